@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Headline benchmark: keypoint-triangulations/s of the fused HIP triangulation path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg4|cfg5|cfg2_clean]
+
+A "step" is one pass of the hot path (p2s_triangulate_device: stage + undistort/mask + weighted
+DLT + camera-subset search) over one synthetic batch that is already resident in HBM.  With
+N > 1 ranks (torchrun, one per GPU) every rank holds its own frame shard of the same size (weak
+scaling) and a step ends with the single all-gather of the packed per-unit results over
+RCCL/xGMI that BASELINE.json's north_star names.  Rank 0 prints ONE JSON line.
+
+The roofline leg times the kernel alone with HIP events on the launch stream; the cpu_baseline
+leg times the CPU oracle (oracle/, a loop-faithful port of the reference) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    'cfg2': dict(workload='synthetic 8-cam x HALPE_26 x 100k frames, single person (BASELINE configs[1])',
+                 F=100_000, C=8, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
+                 undistort=False, lr_swap=False, seed=2),
+    'cfg2_clean': dict(workload='cfg2 without outliers / low-confidence / missing observations',
+                       F=100_000, C=8, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
+                       undistort=False, lr_swap=False, seed=2,
+                       gen=dict(p_lowlik=0.0, p_outlier=0.0, p_missing_cam=0.0)),
+    # per-GPU shard of BASELINE configs[3] (1M frames over 8 GPUs)
+    'cfg4': dict(workload='synthetic 16-cam x COCO_133 (131 kpts) x 125k frames/GPU, min_cameras=3 (BASELINE configs[3] shard)',
+                 F=125_000, C=16, model='COCO_133', Pn=1, thr=15.0, lik=0.3, min_cams=3,
+                 undistort=False, lr_swap=False, seed=4),
+    # per-GPU shard of BASELINE configs[4] (10M frames over 8 GPUs), reduced 10x to keep host generation short
+    'cfg5': dict(workload='synthetic 32-cam x HALPE_26 x 125k frames/GPU, undistort + LR swap (BASELINE configs[4] shard, 1/10 length)',
+                 F=125_000, C=32, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
+                 undistort=True, lr_swap=True, seed=5),
+}
+
+
+def make_workload(cfg, rank):
+    from pose2sim_amd import skeletons, synth
+    ids, names, swap = skeletons.keypoints(cfg['model'])
+    K = len(ids)
+    gen = dict(cfg.get('gen', {}))
+    cams = synth.make_cameras(cfg['C'], seed=cfg['seed'], distort=cfg['undistort'])
+    # frames are generated in chunks to bound host memory; every rank gets different frames
+    F = cfg['F']
+    chunks = []
+    step = 25_000
+    for f0 in range(0, F, step):
+        n = min(step, F - f0)
+        Q3d = synth.make_points3d(n, cfg['Pn'], K, seed=cfg['seed'] + 977 * rank + f0)
+        chunks.append(synth.make_observations(Q3d, cams, seed=cfg['seed'] + 977 * rank + f0,
+                                              distort=cfg['undistort'],
+                                              p_lr_swap=0.02 if cfg['lr_swap'] else 0.0, swap_idx=swap, **gen))
+    xyl = np.concatenate(chunks, axis=0)
+    P = synth.projection_matrices(cams, cfg['undistort'])
+    return xyl, cams, P, np.asarray(swap, dtype=np.int32), K
+
+
+def cpu_baseline(cfg, xyl, cams, P, swap, budget_frames):
+    """The CPU oracle (a loop-faithful NumPy port of the reference) on the first frames."""
+    from oracle import triangulation_ref as tr
+    n = min(budget_frames, xyl.shape[0])
+    t0 = time.perf_counter()
+    tr.triangulate_batch(xyl[:n], P, cams, list(swap), cfg['lik'], cfg['thr'], cfg['min_cams'],
+                         cfg['lr_swap'], cfg['undistort'])
+    dt = time.perf_counter() - t0
+    units = n * xyl.shape[1] * xyl.shape[3]
+    return {'value': units / dt, 'unit': 'keypoint-triangulations/s', 'cores': 1, 'kind': 'port',
+            'sample': f'first {n} frames of the same workload ({units} units, {dt:.1f} s), NumPy oracle, arithmetic only'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build_hip()
+    if world > 1:
+        dist.barrier()
+    from pose2sim_amd.engine import Engine, P2S_F32
+
+    cfg = CONFIGS[args.config]
+    xyl, cams, P, swap, K = make_workload(cfg, rank)
+    F, Pn, C = xyl.shape[0], xyl.shape[1], xyl.shape[2]
+    n_blocks = F * Pn
+    n_units = n_blocks * K
+
+    dev = torch.device('cuda', local_rank)
+    eng = Engine(local_rank)
+    eng.set_calibration(P, cams)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    prm = Engine.tri_params(cfg['thr'], cfg['lik'], cfg['min_cams'], cfg['undistort'], cfg['lr_swap'])
+
+    d_xyl = torch.from_numpy(xyl).to(dev)
+    d_swap = torch.from_numpy(swap).to(dev)
+    # packed result buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8] -> one all-gather
+    off_e = n_units * 24
+    off_m = off_e + n_units * 4
+    off_n = off_m + n_units * 4
+    nbytes = (off_n + n_units + 15) // 16 * 16
+    d_out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    base = d_out.data_ptr()
+    d_all = torch.empty(nbytes * world, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, base, base + off_e, base + off_n, base + off_m)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    def kernel_only():
+        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, base, base + off_e, base + off_n, base + off_m)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline leg: the kernel alone, HIP events on the launch stream
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(args.steps):
+        kernel_only()
+    ev1.record()
+    torch.cuda.synchronize()
+    k_ms = ev0.elapsed_time(ev1) / args.steps
+
+    # sanity: the timed work produced results
+    err = d_out[off_e:off_e + n_units * 4].view(torch.float32)
+    ok_frac = float((~torch.isnan(err)).float().mean().item())
+
+    if rank == 0:
+        alg_bytes = n_units * (12 * C + 32)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.config)
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'keypoint-triangulations/sec',
+            'value': n_units * world * args.steps / dt,
+            'unit': 'keypoint-triangulations/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': cfg['workload'], 'frames_per_gpu': F, 'cams': C, 'kpts': K, 'persons': Pn,
+                       'units_per_gpu': n_units, 'input_dtype': 'f32',
+                       'params': {'thr_px': cfg['thr'], 'lik_thr': cfg['lik'], 'min_cams': cfg['min_cams'],
+                                  'undistort': cfg['undistort'], 'lr_swap': cfg['lr_swap']},
+                       'accepted_fraction': ok_frac, 'tile': eng.tri_geometry(K),
+                       'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step' if world > 1 else '')},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'p2s_tri_kernel', 'kernel_ms': k_ms,
+                         'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            frames = args.cpu_frames or {8: 400, 16: 12, 32: 8}.get(C, 100)
+            out['cpu_baseline'] = cpu_baseline(cfg, xyl, cams, P, swap, frames)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,142 @@
+/*
+ * p2s.h -- C-ABI of the MI355X-native multi-view triangulation / person-association engine.
+ *
+ * Drop-in boundary for the hot path of Pose2Sim.triangulation() / Pose2Sim.personAssociation().
+ * The reference is pure Python with no FFI of its own; each entry point below replaces the inner
+ * loops of one reference function (citations relative to /root/reference/Pose2Sim/) and is what a
+ * reference-side ctypes binding would call (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions cross the ABI; every call returns a status
+ *     (0 = ok, <0 = error) and p2s_last_error() returns the message of the calling thread's
+ *     last failure.
+ *   - one context per GPU per process; a context is not re-entrant.
+ *   - "_device" entry points take DEVICE pointers and enqueue on the context's stream without
+ *     synchronising; "_host" entry points take HOST pointers, copy in/out and block.
+ *   - observation tensor layout: xyl[n_blocks][C][K][3] (x px, y px, likelihood), one block
+ *     per (frame, person); NaN = missing.  dtype float32 or float64 (P2S_F32 / P2S_F64).
+ *   - camera count C <= P2S_MAX_CAMS (the excluded-camera set is returned as a 32-bit mask).
+ */
+#ifndef P2S_H
+#define P2S_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2S_MAX_CAMS 32
+#define P2S_MAX_PERSONS_TOTAL 64   /* association: sum over cameras of detected persons per frame */
+
+#define P2S_OK 0
+#define P2S_ERR_INVALID_ARG (-1)
+#define P2S_ERR_HIP (-2)
+#define P2S_ERR_NO_DEVICE (-3)
+#define P2S_ERR_NO_CALIB (-4)
+#define P2S_ERR_OOM (-5)
+
+#define P2S_F32 0
+#define P2S_F64 1
+
+typedef struct p2s_ctx p2s_ctx;
+
+/* Parameters of triangulation_from_best_cameras (triangulation.py:389-393) plus the likelihood
+ * mask applied by its caller (triangulation.py:686, 817-821). */
+typedef struct p2s_tri_params {
+    double reproj_error_threshold;  /* [triangulation] reproj_error_threshold_triangulation, px */
+    double likelihood_threshold;    /* [triangulation] likelihood_threshold_triangulation       */
+    int32_t min_cameras;            /* [triangulation] min_cameras_for_triangulation (>= 1)     */
+    int32_t undistort_points;       /* [triangulation] undistort_points  (0/1)                  */
+    int32_t handle_lr_swap;         /* [triangulation] handle_LR_swap    (0/1)                  */
+    int32_t reserved;
+} p2s_tri_params;
+
+/* Parameters of the multi-person association (personAssociation.py:670-673, 799-801). */
+typedef struct p2s_assoc_params {
+    double reconstruction_error_threshold; /* [personAssociation.multi_person], metres */
+    double min_affinity;                   /* [personAssociation.multi_person]         */
+    int32_t min_cameras;                   /* [triangulation] min_cameras_for_triangulation */
+    int32_t max_iter;                      /* matchSVT max_iter (reference: 20)  */
+    double w_rank;                         /* matchSVT w_rank   (reference: 50)  */
+    double tol;                            /* matchSVT tol      (reference: 1e-4)*/
+    double w_sparse;                       /* matchSVT w_sparse (reference: 0.1) */
+} p2s_assoc_params;
+
+int p2s_version(void);
+const char *p2s_last_error(void);
+
+/* Number of visible HIP devices (0 without a GPU; never fails the process). */
+int p2s_device_count(int *count);
+
+/* Create / destroy the per-GPU context (device buffers, stream, calibration). */
+int p2s_create(int device_id, p2s_ctx **out);
+int p2s_destroy(p2s_ctx *ctx);
+
+/* Enqueue on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream; NULL = HIP's
+ * default stream).  A fresh context uses a private non-blocking stream. */
+int p2s_set_stream(p2s_ctx *ctx, void *hip_stream);
+int p2s_synchronize(p2s_ctx *ctx);
+
+/* Calibration of C cameras, the outputs of computeP (common.py:291-324) and
+ * retrieve_calib_params (common.py:254-288), all HOST pointers, float64, row-major:
+ *   P[C][12]      projection matrices (built from optim_K when undistorting)
+ *   Kmat[C][9]    original intrinsics               (may be NULL if never undistorting/associating)
+ *   dist[C][5]    k1,k2,p1,p2,k3                    (may be NULL)
+ *   Rmat[C][9]    rotation matrices                 (may be NULL)
+ *   T[C][3]       translations                      (may be NULL)
+ *   newK[C][9]    optim_K                           (may be NULL)
+ */
+int p2s_set_calibration(p2s_ctx *ctx, int32_t n_cams, const double *P, const double *Kmat,
+                        const double *dist, const double *Rmat, const double *T, const double *newK);
+
+/* Robust triangulation of every (block, keypoint) unit: replaces the frame / person / keypoint
+ * loops of triangulate_all (triangulation.py:796-845) around triangulation_from_best_cameras
+ * (triangulation.py:363-604), including undistortion (:808-813) and the likelihood mask
+ * (:817-821).
+ *   xyl       [n_blocks][C][K][3], dtype P2S_F32 or P2S_F64
+ *   swap_idx  [K] keypoints_idx_swapped (triangulation.py:745); may be NULL when !handle_lr_swap
+ * outputs, one per unit u = block*K + k:
+ *   Q        [n][3] float64  3D point (NaN when rejected)
+ *   err      [n]    float32  mean reprojection error px (NaN when rejected)
+ *   n_excl   [n]    uint8    nb_cams_excluded
+ *   excl_mask[n]    uint32   bit c set <=> camera c in id_excluded_cams
+ */
+int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32_t dtype,
+                           const void *d_xyl, const int32_t *d_swap_idx, const p2s_tri_params *params,
+                           double *d_Q, float *d_err, uint8_t *d_n_excl, uint32_t *d_excl_mask);
+int p2s_triangulate_host(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32_t dtype,
+                         const void *xyl, const int32_t *swap_idx, const p2s_tri_params *params,
+                         double *Q, float *err, uint8_t *n_excl, uint32_t *excl_mask);
+
+/* Multi-person association of every frame: replaces the per-frame body of associate_all
+ * (personAssociation.py:783-801): compute_rays (:277-316), compute_affinity (:347-408),
+ * circular_constraint (:411-428), matchSVT (:450-509) and the min_affinity cut (:800).
+ *   n_persons [F][C]  int32   persons detected per camera (read_json, :260-274)
+ *   offsets   [F+1]   int64   start of each frame's rows in kpts (rows = sum_c n_persons[f][c])
+ *   kpts      [rows][Kj][3]   dtype P2S_F32/P2S_F64: camera-major, then person, JSON keypoint order
+ * output:
+ *   affinity  [F][Nmax][Nmax] float64, the thresholded matchSVT result, top-left N_f x N_f valid
+ *             (N_f = sum_c n_persons[f][c] <= Nmax <= P2S_MAX_PERSONS_TOTAL)
+ * The order-sensitive proposal extraction (person_index_per_cam, :512-549) stays on the host.
+ */
+int p2s_associate_device(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, int32_t n_max, int32_t dtype,
+                         const int32_t *d_n_persons, const int64_t *d_offsets, const void *d_kpts,
+                         const p2s_assoc_params *params, double *d_affinity);
+int p2s_associate_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, int32_t n_max, int32_t dtype,
+                       const int32_t *n_persons, const int64_t *offsets, const void *kpts,
+                       const p2s_assoc_params *params, double *affinity);
+
+/* Kernel timing on the context's stream with HIP events: begin, enqueue work, end (blocks). */
+int p2s_timing_begin(p2s_ctx *ctx);
+int p2s_timing_end(p2s_ctx *ctx, float *elapsed_ms);
+
+/* Tile geometry the triangulation kernel will use for (C, K, dtype): diagnostics for DESIGN.md /
+ * bench.py (blocks per tile, threads per workgroup, LDS bytes). */
+int p2s_tri_geometry(int32_t n_cams, int32_t n_kpts, int32_t dtype, int32_t *blocks_per_tile,
+                     int32_t *threads, int32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2S_H */

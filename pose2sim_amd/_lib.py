@@ -1,0 +1,93 @@
+"""ctypes binding of the C-ABI in include/p2s.h (csrc/libp2s_hip.so).
+
+The library is the only compute path: there is no CPU fallback.  ``load()`` raises if the shared
+object is missing; ``Context()`` raises if no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2s_hip.so')
+
+P2S_F32, P2S_F64 = 0, 1
+P2S_MAX_CAMS = 32
+P2S_MAX_PERSONS_TOTAL = 64
+
+
+class TriParams(C.Structure):
+    _fields_ = [('reproj_error_threshold', C.c_double),
+                ('likelihood_threshold', C.c_double),
+                ('min_cameras', C.c_int32),
+                ('undistort_points', C.c_int32),
+                ('handle_lr_swap', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class AssocParams(C.Structure):
+    _fields_ = [('reconstruction_error_threshold', C.c_double),
+                ('min_affinity', C.c_double),
+                ('min_cameras', C.c_int32),
+                ('max_iter', C.c_int32),
+                ('w_rank', C.c_double),
+                ('tol', C.c_double),
+                ('w_sparse', C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/p2s.h declares
+SIGNATURES = {
+    'p2s_version': (C.c_int, []),
+    'p2s_last_error': (C.c_char_p, []),
+    'p2s_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'p2s_create': (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    'p2s_destroy': (C.c_int, [C.c_void_p]),
+    'p2s_set_stream': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'p2s_synchronize': (C.c_int, [C.c_void_p]),
+    'p2s_set_calibration': (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 6),
+    'p2s_triangulate_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                         C.POINTER(TriParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'p2s_triangulate_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.POINTER(TriParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'p2s_associate_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(AssocParams), C.c_void_p]),
+    'p2s_associate_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.POINTER(AssocParams), C.c_void_p]),
+    'p2s_timing_begin': (C.c_int, [C.c_void_p]),
+    'p2s_timing_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'p2s_tri_geometry': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+class P2sError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libp2s_hip.so and bind every entry point; raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise P2sError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().p2s_last_error()
+        raise P2sError(f'p2s error {rc}: {msg.decode() if msg else "?"}')
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().p2s_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,359 @@
+// p2s_api.hip -- the extern "C" boundary declared in include/p2s.h.
+//
+// Owns the per-GPU context (stream, calibration, scratch) and validates operand shapes on the
+// host before any kernel is launched.  No torch types, no exceptions across the ABI.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "p2s.h"
+#include "p2s_internal.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? P2S_ERR_OOM : P2S_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                    \
+    } while (0)
+
+struct Scratch {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t n) {
+        if (n <= bytes) return P2S_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return fail(P2S_ERR_OOM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        bytes = n;
+        return P2S_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct p2s_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    P2sCam *d_cams = nullptr;
+    uint32_t *d_binom = nullptr;
+    int n_cams = 0;
+    bool full_calib = false;     // K, dist, R, T, newK were provided
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Scratch in, swap, q, err, nexcl, mask, aux0, aux1;
+};
+
+namespace {
+
+struct Geometry {
+    int FB, threads, lds_bytes, lds_P_off, lds_binom_off, G;
+};
+
+int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+
+// Tile geometry: FB consecutive (frame, person) blocks per workgroup.  The tile start must stay
+// 16-byte aligned for the dwordx4 staging loads, the lanes of a workgroup should be nearly all
+// busy (FB*K close to a multiple of 64), and several workgroups should fit the CU's 160 KB LDS.
+Geometry choose_geometry(int C, int K, int dtype) {
+    const int elem = dtype == P2S_F32 ? 4 : 8;
+    const long blk_bytes = (long)C * K * 3 * elem;
+    const int step = 16 / gcd_i(16, (int)(blk_bytes % 16 == 0 ? 16 : blk_bytes % 16));
+    const int extra = ((C * 12 * 8 + 15) / 16) * 16 + 33 * 33 * 4;
+    Geometry best{};
+    double best_score = -1.0;
+    for (int FB = step; FB <= 4096; FB += step) {
+        const long tile = FB * blk_bytes;
+        const long tile_al = (tile + 15) / 16 * 16;
+        const long lds = tile_al + extra;
+        if (lds > 150 * 1024) break;
+        const long units = (long)FB * K;
+        const int threads = (int)std::min<long>(1024, (units + 63) / 64 * 64);
+        const long passes = (units + threads - 1) / threads;
+        const double eff = (double)units / (double)(passes * threads);
+        const int wg_per_cu = (int)std::min<long>(8, (160 * 1024) / lds);
+        const int waves = std::min(32, wg_per_cu * threads / 64);
+        double score = eff * std::min(1.0, waves / 12.0);
+        if (lds > 64 * 1024) score *= 0.8;
+        if (passes > 1) score *= 0.9;
+        if (score > best_score + 1e-9) {
+            best_score = score;
+            best.FB = FB;
+            best.threads = threads;
+            best.lds_bytes = (int)lds;
+            best.lds_P_off = (int)tile_al;
+            best.lds_binom_off = (int)tile_al + ((C * 12 * 8 + 15) / 16) * 16;
+        }
+    }
+    if (best_score < 0) {   // a single block does not fit: not supported
+        best.FB = 0;
+    }
+    int G = 4;
+    while (G < C) G <<= 1;
+    best.G = G;
+    return best;
+}
+
+void fill_binom(uint32_t *b) {
+    for (int n = 0; n < 33; ++n)
+        for (int k = 0; k < 33; ++k) {
+            unsigned long long v;
+            if (k > n) v = 0;
+            else if (k == 0 || k == n) v = 1;
+            else v = (unsigned long long)b[(n - 1) * 33 + k - 1] + b[(n - 1) * 33 + k];
+            b[n * 33 + k] = (uint32_t)std::min<unsigned long long>(v, 0xfffffffeull);
+        }
+}
+
+int check_tri(p2s_ctx *ctx, int64_t n_blocks, int32_t K, int32_t dtype, const p2s_tri_params *p,
+              const void *swap_idx) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (ctx->n_cams <= 0) return fail(P2S_ERR_NO_CALIB, "p2s_set_calibration has not been called");
+    if (!p) return fail(P2S_ERR_INVALID_ARG, "null params");
+    if (n_blocks < 0 || K <= 0) return fail(P2S_ERR_INVALID_ARG, "bad shape: n_blocks=%lld K=%d", (long long)n_blocks, K);
+    if (dtype != P2S_F32 && dtype != P2S_F64) return fail(P2S_ERR_INVALID_ARG, "dtype must be P2S_F32 or P2S_F64");
+    if (p->min_cameras < 1) return fail(P2S_ERR_INVALID_ARG, "min_cameras must be >= 1 (got %d)", p->min_cameras);
+    if (!(p->reproj_error_threshold == p->reproj_error_threshold))
+        return fail(P2S_ERR_INVALID_ARG, "reproj_error_threshold is NaN");
+    if (p->undistort_points && !ctx->full_calib)
+        return fail(P2S_ERR_NO_CALIB, "undistort_points needs K, dist, R, T and optim_K in p2s_set_calibration");
+    if (p->handle_lr_swap && !swap_idx) return fail(P2S_ERR_INVALID_ARG, "handle_lr_swap needs swap_idx");
+    if (n_blocks * (int64_t)K >= (int64_t)1 << 40) return fail(P2S_ERR_INVALID_ARG, "too many units");
+    return P2S_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int p2s_version(void) { return 100; }
+
+const char *p2s_last_error(void) { return g_last_error.c_str(); }
+
+int p2s_device_count(int *count) {
+    if (!count) return fail(P2S_ERR_INVALID_ARG, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return P2S_OK;
+}
+
+int p2s_create(int device_id, p2s_ctx **out) {
+    if (!out) return fail(P2S_ERR_INVALID_ARG, "null out");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(P2S_ERR_NO_DEVICE, "no HIP device visible: the triangulation engine has no CPU fallback");
+    }
+    if (device_id < 0 || device_id >= n) return fail(P2S_ERR_INVALID_ARG, "device %d out of range (%d devices)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    p2s_ctx *c = new p2s_ctx();
+    c->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipMalloc((void **)&c->d_cams, sizeof(P2sCam) * P2S_MAX_CAMS));
+    HIP_TRY(hipMalloc((void **)&c->d_binom, sizeof(uint32_t) * 33 * 33));
+    std::vector<uint32_t> b(33 * 33);
+    fill_binom(b.data());
+    HIP_TRY(hipMemcpy(c->d_binom, b.data(), b.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    *out = c;
+    return P2S_OK;
+}
+
+int p2s_destroy(p2s_ctx *ctx) {
+    if (!ctx) return P2S_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->in.release(); ctx->swap.release(); ctx->q.release(); ctx->err.release();
+    ctx->nexcl.release(); ctx->mask.release(); ctx->aux0.release(); ctx->aux1.release();
+    if (ctx->d_cams) (void)hipFree(ctx->d_cams);
+    if (ctx->d_binom) (void)hipFree(ctx->d_binom);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return P2S_OK;
+}
+
+int p2s_set_stream(p2s_ctx *ctx, void *hip_stream) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    ctx->stream = (hipStream_t)hip_stream;   // NULL = HIP's default stream
+    return P2S_OK;
+}
+
+int p2s_synchronize(p2s_ctx *ctx) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_set_calibration(p2s_ctx *ctx, int32_t n_cams, const double *P, const double *Kmat, const double *dist,
+                        const double *Rmat, const double *T, const double *newK) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (n_cams < 1 || n_cams > P2S_MAX_CAMS) return fail(P2S_ERR_INVALID_ARG, "n_cams=%d outside [1, %d]", n_cams, P2S_MAX_CAMS);
+    if (!P) return fail(P2S_ERR_INVALID_ARG, "null P");
+    const bool full = Kmat && dist && Rmat && T && newK;
+    if (!full && (Kmat || dist || Rmat || T || newK))
+        return fail(P2S_ERR_INVALID_ARG, "K, dist, R, T and optim_K must be given together or all be NULL");
+    std::vector<P2sCam> cams(P2S_MAX_CAMS);
+    std::memset(cams.data(), 0, sizeof(P2sCam) * P2S_MAX_CAMS);
+    for (int c = 0; c < n_cams; ++c) {
+        P2sCam &cam = cams[c];
+        std::memcpy(cam.P, P + 12 * c, sizeof cam.P);
+        if (!full) continue;
+        const double *K = Kmat + 9 * c;
+        cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+        cam.ifx = 1.0 / cam.fx; cam.ify = 1.0 / cam.fy;
+        std::memcpy(cam.k, dist + 5 * c, sizeof cam.k);
+        std::memcpy(cam.R, Rmat + 9 * c, sizeof cam.R);
+        std::memcpy(cam.T, T + 3 * c, sizeof cam.T);
+        std::memcpy(cam.nk, newK + 9 * c, sizeof cam.nk);
+        // inverse of K (general 3x3, as numpy.linalg.inv at common.py:282) by cofactors
+        const double a = K[0], b = K[1], cc = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], i = K[8];
+        const double det = a * (e * i - f * h) - b * (d * i - f * g) + cc * (d * h - e * g);
+        const double id = 1.0 / det;
+        cam.iK[0] = (e * i - f * h) * id; cam.iK[1] = (cc * h - b * i) * id; cam.iK[2] = (b * f - cc * e) * id;
+        cam.iK[3] = (f * g - d * i) * id; cam.iK[4] = (a * i - cc * g) * id; cam.iK[5] = (cc * d - a * f) * id;
+        cam.iK[6] = (d * h - e * g) * id; cam.iK[7] = (b * g - a * h) * id; cam.iK[8] = (a * e - b * d) * id;
+        for (int r = 0; r < 3; ++r)
+            cam.center[r] = -(cam.R[0 * 3 + r] * cam.T[0] + cam.R[1 * 3 + r] * cam.T[1] + cam.R[2 * 3 + r] * cam.T[2]);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(ctx->d_cams, cams.data(), sizeof(P2sCam) * P2S_MAX_CAMS, hipMemcpyHostToDevice));
+    ctx->n_cams = n_cams;
+    ctx->full_calib = full;
+    return P2S_OK;
+}
+
+int p2s_tri_geometry(int32_t n_cams, int32_t n_kpts, int32_t dtype, int32_t *blocks_per_tile, int32_t *threads,
+                     int32_t *lds_bytes) {
+    if (n_cams < 1 || n_cams > P2S_MAX_CAMS || n_kpts < 1 || (dtype != P2S_F32 && dtype != P2S_F64))
+        return fail(P2S_ERR_INVALID_ARG, "bad geometry query");
+    Geometry g = choose_geometry(n_cams, n_kpts, dtype);
+    if (g.FB == 0) return fail(P2S_ERR_INVALID_ARG, "one block of C=%d x K=%d does not fit in LDS", n_cams, n_kpts);
+    if (blocks_per_tile) *blocks_per_tile = g.FB;
+    if (threads) *threads = g.threads;
+    if (lds_bytes) *lds_bytes = g.lds_bytes;
+    return P2S_OK;
+}
+
+int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32_t dtype, const void *d_xyl,
+                           const int32_t *d_swap_idx, const p2s_tri_params *params, double *d_Q, float *d_err,
+                           uint8_t *d_n_excl, uint32_t *d_excl_mask) {
+    int rc = check_tri(ctx, n_blocks, n_kpts, dtype, params, d_swap_idx);
+    if (rc != P2S_OK) return rc;
+    if (n_blocks == 0) return P2S_OK;
+    if (!d_xyl || !d_Q || !d_err || !d_n_excl || !d_excl_mask) return fail(P2S_ERR_INVALID_ARG, "null device pointer");
+    if (((uintptr_t)d_xyl & 15) != 0) return fail(P2S_ERR_INVALID_ARG, "xyl must be 16-byte aligned");
+    const int C = ctx->n_cams;
+    Geometry g = choose_geometry(C, n_kpts, dtype);
+    if (g.FB == 0) return fail(P2S_ERR_INVALID_ARG, "one block of C=%d x K=%d does not fit in LDS", C, n_kpts);
+    const int64_t n_tiles = (n_blocks + g.FB - 1) / g.FB;
+    if (n_tiles > 0x7fffffffLL) return fail(P2S_ERR_INVALID_ARG, "too many tiles (%lld)", (long long)n_tiles);
+
+    P2sTriArgs a{};
+    a.xyl = d_xyl;
+    a.swap_idx = d_swap_idx;
+    a.Q = d_Q; a.err = d_err; a.n_excl = d_n_excl; a.mask = d_excl_mask;
+    a.cams = ctx->d_cams;
+    a.binom = ctx->d_binom;
+    a.n_blocks = n_blocks;
+    a.K = n_kpts; a.C = C; a.FB = g.FB; a.G = g.G;
+    a.lds_P_off = g.lds_P_off; a.lds_binom_off = g.lds_binom_off;
+    a.min_cams = params->min_cameras;
+    a.undistort = params->undistort_points ? 1 : 0;
+    a.lr_swap = params->handle_lr_swap ? 1 : 0;
+    a.thr = params->reproj_error_threshold;
+    a.lik_thr = params->likelihood_threshold;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(p2s_launch_tri(a, dtype, (int)n_tiles, g.threads, (size_t)g.lds_bytes, ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_triangulate_host(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32_t dtype, const void *xyl,
+                         const int32_t *swap_idx, const p2s_tri_params *params, double *Q, float *err,
+                         uint8_t *n_excl, uint32_t *excl_mask) {
+    int rc = check_tri(ctx, n_blocks, n_kpts, dtype, params, swap_idx);
+    if (rc != P2S_OK) return rc;
+    if (n_blocks == 0) return P2S_OK;
+    if (!xyl || !Q || !err || !n_excl || !excl_mask) return fail(P2S_ERR_INVALID_ARG, "null host pointer");
+    const int C = ctx->n_cams;
+    const size_t elem = dtype == P2S_F32 ? 4 : 8;
+    const size_t n_units = (size_t)n_blocks * n_kpts;
+    const size_t in_bytes = (size_t)n_blocks * C * n_kpts * 3 * elem;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.ensure(in_bytes)) != P2S_OK) return rc;
+    if ((rc = ctx->q.ensure(n_units * 24)) != P2S_OK) return rc;
+    if ((rc = ctx->err.ensure(n_units * 4)) != P2S_OK) return rc;
+    if ((rc = ctx->nexcl.ensure(n_units)) != P2S_OK) return rc;
+    if ((rc = ctx->mask.ensure(n_units * 4)) != P2S_OK) return rc;
+    const int32_t *d_swap = nullptr;
+    if (swap_idx) {
+        if ((rc = ctx->swap.ensure((size_t)n_kpts * 4)) != P2S_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->swap.p, swap_idx, (size_t)n_kpts * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_swap = (const int32_t *)ctx->swap.p;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->in.p, xyl, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = p2s_triangulate_device(ctx, n_blocks, n_kpts, dtype, ctx->in.p, d_swap, params, (double *)ctx->q.p,
+                                (float *)ctx->err.p, (uint8_t *)ctx->nexcl.p, (uint32_t *)ctx->mask.p);
+    if (rc != P2S_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(Q, ctx->q.p, n_units * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(err, ctx->err.p, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(n_excl, ctx->nexcl.p, n_units, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(excl_mask, ctx->mask.p, n_units * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_timing_begin(p2s_ctx *ctx) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_timing_end(p2s_ctx *ctx, float *elapsed_ms) {
+    if (!ctx || !elapsed_ms) return fail(P2S_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return P2S_OK;
+}
+
+}  // extern "C"

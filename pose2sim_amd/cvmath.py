@@ -61,10 +61,11 @@ def undistort_normalized(u, v, K, dist, iters=5):
     K = np.asarray(K, dtype=np.float64)
     k = _dist12(dist)
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    ifx, ify = 1.0 / fx, 1.0 / fy          # OpenCV multiplies by precomputed reciprocals
     u = np.asarray(u, dtype=np.float64)
     v = np.asarray(v, dtype=np.float64)
-    x0 = (u - cx) / fx
-    y0 = (v - cy) / fy
+    x0 = (u - cx) * ifx
+    y0 = (v - cy) * ify
     x, y = x0.copy(), y0.copy()
     done = np.zeros(x.shape, dtype=bool)
     for _ in range(iters):

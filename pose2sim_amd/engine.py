@@ -1,0 +1,135 @@
+"""Python face of the HIP engine: one ``Engine`` per GPU, thin wrappers over the C-ABI.
+
+Host arrays are NumPy (the library copies them in and out); device-resident operands are passed
+as raw pointers (``tensor.data_ptr()``), with torch used only as the allocator / stream owner.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import P2S_F32, P2S_F64, AssocParams, P2sError, TriParams  # noqa: F401
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, 'data_ptr'):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+def as_packed(xyl):
+    """Pick the narrowest exact dtype for an observation tensor: float32 when every value is
+    float32-representable (RTMLib output is, poseEstimation.py:259), else float64, so that the
+    kernel sees exactly the numbers the reference would read from the JSON files."""
+    xyl = np.asarray(xyl)
+    if xyl.dtype == np.float32:
+        return np.ascontiguousarray(xyl), P2S_F32
+    x64 = np.ascontiguousarray(xyl, dtype=np.float64)
+    x32 = x64.astype(np.float32)
+    same = (x32.astype(np.float64) == x64) | np.isnan(x64)
+    if same.all():
+        return x32, P2S_F32
+    return x64, P2S_F64
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.p2s_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.n_cams = 0
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.p2s_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- calibration -----------------------------------------------------------------------
+    def set_calibration(self, P, cal=None):
+        """P: C projection matrices (3x4).  cal: dict with 'K', 'dist', 'R_mat', 'T', 'optim_K'
+        lists (retrieve_calib_params, common.py:254-288) -- needed for undistortion / association."""
+        P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 12))
+        n = P.shape[0]
+        args = [None] * 5
+        keep = [P]
+        if cal is not None:
+            K = np.ascontiguousarray(np.asarray(cal['K'], dtype=np.float64).reshape(n, 9))
+            d = np.zeros((n, 5))
+            for c in range(n):
+                dc = np.asarray(cal['dist'][c], dtype=np.float64).ravel()
+                if len(dc) > 5 and np.any(dc[5:] != 0):
+                    raise P2sError('only k1,k2,p1,p2[,k3] distortion terms are supported')
+                d[c, :min(5, len(dc))] = dc[:5]
+            R = np.ascontiguousarray(np.asarray(cal['R_mat'], dtype=np.float64).reshape(n, 9))
+            T = np.ascontiguousarray(np.asarray(cal['T'], dtype=np.float64).reshape(n, 3))
+            nk = np.ascontiguousarray(np.asarray(cal['optim_K'], dtype=np.float64).reshape(n, 9))
+            keep += [K, d, R, T, nk]
+            args = [_ptr(K), _ptr(d), _ptr(R), _ptr(T), _ptr(nk)]
+        _lib.check(self._lib.p2s_set_calibration(self._h, n, _ptr(P), *args))
+        self.n_cams = n
+
+    def set_stream(self, stream_handle):
+        """Enqueue on this HIP stream (0 / None = HIP's default stream, which is torch's default)."""
+        _lib.check(self._lib.p2s_set_stream(self._h, C.c_void_p(int(stream_handle or 0))))
+
+    def synchronize(self):
+        _lib.check(self._lib.p2s_synchronize(self._h))
+
+    # -- triangulation ---------------------------------------------------------------------
+    @staticmethod
+    def tri_params(thr, lik_thr, min_cams, undistort=False, lr_swap=False):
+        return TriParams(float(thr), float(lik_thr), int(min_cams), int(bool(undistort)), int(bool(lr_swap)), 0)
+
+    def triangulate(self, xyl, params, swap_idx=None):
+        """xyl: [..., C, K, 3] float32/float64 host array (leading dims = frames x persons).
+        Returns Q [..., K, 3] f64, err [..., K] f32, n_excl [..., K] u8, mask [..., K] u32."""
+        xyl, dtype = as_packed(xyl)
+        Cn, K = xyl.shape[-3], xyl.shape[-2]
+        if Cn != self.n_cams or xyl.shape[-1] != 3:
+            raise P2sError(f'xyl has shape {xyl.shape}; expected [..., {self.n_cams}, K, 3]')
+        lead = xyl.shape[:-3]
+        nb = int(np.prod(lead)) if lead else 1
+        Q = np.empty((nb, K, 3), dtype=np.float64)
+        err = np.empty((nb, K), dtype=np.float32)
+        nex = np.empty((nb, K), dtype=np.uint8)
+        mask = np.empty((nb, K), dtype=np.uint32)
+        sw = None
+        if swap_idx is not None:
+            sw = np.ascontiguousarray(np.asarray(swap_idx, dtype=np.int32))
+            if sw.shape != (K,) or sw.min() < 0 or sw.max() >= K:
+                raise P2sError('swap_idx must be K indices in [0, K)')
+        _lib.check(self._lib.p2s_triangulate_host(self._h, nb, K, dtype, _ptr(xyl), _ptr(sw), C.byref(params),
+                                                  _ptr(Q), _ptr(err), _ptr(nex), _ptr(mask)))
+        return (Q.reshape(lead + (K, 3)), err.reshape(lead + (K,)), nex.reshape(lead + (K,)),
+                mask.reshape(lead + (K,)))
+
+    def triangulate_device(self, n_blocks, K, dtype, d_xyl, d_swap, params, d_Q, d_err, d_nexcl, d_mask):
+        """Device-resident operands (tensors or raw pointers); enqueues on the engine's stream."""
+        _lib.check(self._lib.p2s_triangulate_device(self._h, int(n_blocks), int(K), int(dtype), _ptr(d_xyl),
+                                                    _ptr(d_swap), C.byref(params), _ptr(d_Q), _ptr(d_err),
+                                                    _ptr(d_nexcl), _ptr(d_mask)))
+
+    def timing_begin(self):
+        _lib.check(self._lib.p2s_timing_begin(self._h))
+
+    def timing_end(self):
+        ms = C.c_float(0)
+        _lib.check(self._lib.p2s_timing_end(self._h, C.byref(ms)))
+        return ms.value
+
+    def tri_geometry(self, K, dtype=P2S_F32):
+        fb, th, lds = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._lib.p2s_tri_geometry(self.n_cams, int(K), int(dtype), C.byref(fb), C.byref(th), C.byref(lds)))
+        return {'blocks_per_tile': fb.value, 'threads': th.value, 'lds_bytes': lds.value}

@@ -97,7 +97,7 @@ def gen_triangulation_units():
                 mo[u] = m
                 u += 1
         g = dict(C=C, min_cams=min_cams, lr_swap=lr_swap, undistort=undistort, lik_thr=lik_thr, thr=thr,
-                 raw_xyl=wl['xyl'], coords=coords, coords_sw=coords_sw, P=np.array(P),
+                 raw_xyl=xyl.astype(np.float32), coords=coords, coords_sw=coords_sw, P=np.array(P),
                  K=np.array(cams['K']), dist=np.array(cams['dist']), R=np.array(cams['R']),
                  T=np.array(cams['T']), optim_K=np.array(cams['optim_K']),
                  Q=Qo, err=eo, n_excl=no, mask=mo)

@@ -45,3 +45,42 @@ def test_unit_oracle_matches_reference(golden_dir):
                 assert np.isnan(Q).all()
             total += 1
     assert total > 1500
+
+
+def test_c_oracle_matches_reference(golden_dir):
+    """The compiled restatement (oracle/tri_oracle.c) on the same recorded units, fed through the
+    batch entry point (raw float32 observations -> undistort -> mask -> search)."""
+    from oracle import tri_oracle
+    from pose2sim_amd import cvmath, skeletons
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    worst = 0.0
+    for i, g in _groups(golden_dir):
+        C = int(g['C'])
+        cams = _cal(g)
+        cams['R_mat'] = [cvmath.rodrigues(r) for r in cams['R']]
+        Q, e, ne, mask = tri_oracle.triangulate_batch(
+            g['raw_xyl'], [g['P'][c] for c in range(C)], cams, swap, float(g['lik_thr']), float(g['thr']),
+            int(g['min_cams']), bool(g['lr_swap']), bool(g['undistort']), threads=4)
+        Q = Q.reshape(-1, 3); e = e.reshape(-1); ne = ne.reshape(-1); mask = mask.reshape(-1)
+        assert np.array_equal(ne, g['n_excl']), i
+        assert np.array_equal(mask, g['mask']), i
+        assert np.array_equal(np.isnan(e), np.isnan(g['err'])), i
+        ok = ~np.isnan(e)
+        assert np.abs(e[ok] - g['err'][ok]).max() <= 1e-9 * max(1.0, np.abs(e[ok]).max()), i
+        worst = max(worst, np.abs(Q[ok] - g['Q'][ok]).max())
+    assert worst <= 1e-7, worst
+
+
+def test_c_oracle_matches_numpy_oracle_on_fresh_data():
+    from oracle import tri_oracle
+    from pose2sim_amd import skeletons, synth
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    for C, mc, sw, und in [(4, 2, False, False), (6, 3, True, True), (8, 2, True, False)]:
+        wl = synth.make_config(12, C, 26, 1, seed=40 + C, undistort=und, lr_swap=sw, swap_idx=swap,
+                               p_lowlik=0.1, p_outlier=0.08, p_missing_cam=0.03)
+        a = tr.triangulate_batch(wl['xyl'], wl['P'], wl['cams'], swap, 0.3, 12.0, mc, sw, und)
+        b = tri_oracle.triangulate_batch(wl['xyl'], wl['P'], wl['cams'], swap, 0.3, 12.0, mc, sw, und)
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.array_equal(np.isnan(a[1]), np.isnan(b[1]))
+        ok = ~np.isnan(a[1])
+        assert np.abs(a[0][ok] - b[0][ok]).max() <= 1e-9

@@ -1,0 +1,204 @@
+"""GPU parity of the fused triangulation kernel, through the C-ABI.
+
+Bars (BASELINE.json north_star): 3D within 1e-4 mm = 1e-7 m of the reference, identical
+inlier-camera selections (n_excl, excluded-camera mask, NaN pattern) -- checked against
+  * the fixtures recorded from the reference (tests/golden/tri_units.npz),
+  * the CPU oracle on fresh seeded inputs,
+  * size-independent properties at BASELINE config sizes.
+The reprojection error leaves the kernel as float32: tolerance 2e-7 relative (one f32 ulp).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_Q = 1e-7        # metres
+TOL_E = 2e-7        # relative, float32 output
+
+
+@pytest.fixture(scope='module')
+def engine():
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from pose2sim_amd.engine import Engine
+    eng = Engine(0)
+    yield eng
+    eng.close()
+
+
+def _cal_from_group(g):
+    from pose2sim_amd import cvmath
+    C = int(g['C'])
+    return {'K': [g['K'][c] for c in range(C)], 'dist': [g['dist'][c] for c in range(C)],
+            'R': [g['R'][c] for c in range(C)], 'R_mat': [cvmath.rodrigues(g['R'][c]) for c in range(C)],
+            'T': [g['T'][c] for c in range(C)], 'optim_K': [g['optim_K'][c] for c in range(C)]}
+
+
+def _compare(Q, err, nex, mask, Qr, er, nr, mr, what=''):
+    Q = Q.reshape(-1, 3); err = err.reshape(-1); nex = nex.reshape(-1); mask = mask.reshape(-1)
+    Qr = Qr.reshape(-1, 3); er = np.asarray(er, dtype=np.float64).reshape(-1)
+    nr = np.asarray(nr).reshape(-1); mr = np.asarray(mr).reshape(-1)
+    bad = np.flatnonzero(np.isnan(err) != np.isnan(er))
+    assert bad.size == 0, f'{what}: NaN pattern differs at units {bad[:8]}'
+    bad = np.flatnonzero(nex.astype(np.int64) != nr.astype(np.int64))
+    assert bad.size == 0, f'{what}: nb_cams_excluded differs at {bad[:8]}: {nex[bad[:8]]} vs {nr[bad[:8]]}'
+    bad = np.flatnonzero(mask.astype(np.uint32) != mr.astype(np.uint32))
+    assert bad.size == 0, f'{what}: excluded-camera mask differs at {bad[:8]}: {mask[bad[:8]]} vs {mr[bad[:8]]}'
+    ok = ~np.isnan(er)
+    assert np.isnan(Q[~ok]).all()
+    if ok.any():
+        dq = np.abs(Q[ok] - Qr[ok]).max()
+        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m'
+        de = np.abs(err[ok].astype(np.float64) - er[ok]) / np.maximum(1.0, np.abs(er[ok]))
+        assert de.max() <= TOL_E, f'{what}: error differs by {de.max():.3e}'
+        return dq
+    return 0.0
+
+
+def test_golden_units(engine, golden_dir):
+    """Every recorded reference unit (2.4k units, C in 2..16, swap / undistort / zero likelihoods)."""
+    from pose2sim_amd import skeletons
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    z = np.load(os.path.join(golden_dir, 'tri_units.npz'))
+    worst = 0.0
+    for i in range(int(z['n_groups'])):
+        g = {k[len(f'g{i}_'):]: z[k] for k in z.files if k.startswith(f'g{i}_')}
+        C = int(g['C'])
+        engine.set_calibration([g['P'][c] for c in range(C)], _cal_from_group(g))
+        prm = engine.tri_params(float(g['thr']), float(g['lik_thr']), int(g['min_cams']),
+                                bool(g['undistort']), bool(g['lr_swap']))
+        xyl = g['raw_xyl']                     # [F][1][C][K][3] float32
+        Q, err, nex, mask = engine.triangulate(xyl, prm, swap)
+        worst = max(worst, _compare(Q, err, nex, mask, g['Q'], g['err'], g['n_excl'], g['mask'], f'group {i}'))
+    print(f'golden: worst |dQ| = {worst:.3e} m')
+
+
+@pytest.mark.parametrize('C,min_cams,lr_swap,undistort,dtype64', [
+    (4, 2, False, False, False),
+    (8, 2, False, False, False),
+    (8, 3, True, False, False),
+    (5, 2, False, True, False),
+    (6, 2, True, True, False),
+    (8, 2, False, False, True),
+    (3, 2, True, False, True),
+])
+def test_against_oracle(engine, C, min_cams, lr_swap, undistort, dtype64):
+    from oracle import triangulation_ref as tr
+    from pose2sim_amd import skeletons, synth
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    F = 40
+    wl = synth.make_config(F, C, 26, 1, seed=11 + C, undistort=undistort, lr_swap=lr_swap, swap_idx=swap,
+                           p_lowlik=0.08, p_outlier=0.06, p_missing_cam=0.02)
+    xyl = wl['xyl']
+    if dtype64:     # values that are NOT float32-representable must take the float64 path unchanged
+        rng = np.random.default_rng(5)
+        xyl = xyl.astype(np.float64) + rng.uniform(-1e-4, 1e-4, xyl.shape) * (xyl.astype(np.float64) != 0)
+    cams = wl['cams']
+    engine.set_calibration(wl['P'], cams)
+    prm = engine.tri_params(12.0, 0.3, min_cams, undistort, lr_swap)
+    Q, err, nex, mask = engine.triangulate(xyl, prm, swap)
+    Qr, er, nr, mr = tr.triangulate_batch(xyl, wl['P'], cams, swap, 0.3, 12.0, min_cams, lr_swap, undistort)
+    _compare(Q, err, nex, mask, Qr, er, nr, mr, f'C={C}')
+
+
+def test_edge_cases(engine):
+    """Empty input, all-missing units, fewer cameras than min_cameras, ragged last tile, K = 1."""
+    from oracle import triangulation_ref as tr
+    from pose2sim_amd import synth
+    wl = synth.make_config(3, 4, 5, 1, seed=3)
+    engine.set_calibration(wl['P'])
+    prm = engine.tri_params(15.0, 0.3, 2)
+    # empty
+    Q, err, nex, mask = engine.triangulate(np.zeros((0, 4, 5, 3), np.float32), prm)
+    assert Q.shape == (0, 5, 3) and err.shape == (0, 5)
+    # everything missing / below threshold
+    x = wl['xyl'].copy()
+    x[0] = np.nan
+    x[1, :, :, :, 2] = 0.1
+    Q, err, nex, mask = engine.triangulate(x, prm)
+    assert np.isnan(Q[0]).all() and np.isnan(err[0]).all() and (nex[0] == 4).all() and (mask[0] == 0xF).all()
+    assert np.isnan(Q[1]).all() and (nex[1] == 4).all()
+    Qr, er, nr, mr = tr.triangulate_batch(x, wl['P'], None, list(range(5)), 0.3, 15.0, 2)
+    _compare(Q, err, nex, mask, Qr, er, nr, mr, 'missing')
+    # min_cameras above the camera count: no level runs (triangulation.py:408, 595-596)
+    prm5 = engine.tri_params(15.0, 0.3, 5)
+    Q, err, nex, mask = engine.triangulate(wl['xyl'], prm5)
+    assert np.isnan(Q).all() and (nex == 4).all() and (mask == 0xF).all()
+    # ragged tiles: every n_blocks from 1 to 2 tiles + 1, K = 1
+    wl1 = synth.make_config(300, 4, 1, 1, seed=4, p_outlier=0.1)
+    engine.set_calibration(wl1['P'])
+    geo = engine.tri_geometry(1)
+    Qa, ea, na, ma = engine.triangulate(wl1['xyl'], prm)
+    for nb in (1, 2, geo['blocks_per_tile'] - 1, geo['blocks_per_tile'] + 1, 299):
+        nb = max(1, min(nb, 300))
+        Q, err, nex, mask = engine.triangulate(wl1['xyl'][:nb], prm)
+        assert np.array_equal(Q, Qa[:nb], equal_nan=True) and np.array_equal(mask, ma[:nb])
+    Qr, er, nr, mr = tr.triangulate_batch(wl1['xyl'][:60], wl1['P'], None, [0], 0.3, 15.0, 2)
+    _compare(Qa[:60], ea[:60], na[:60], ma[:60], Qr, er, nr, mr, 'K=1')
+
+
+def test_bad_arguments(engine):
+    from pose2sim_amd._lib import P2sError
+    from pose2sim_amd import synth
+    wl = synth.make_config(2, 4, 5, 1, seed=3)
+    engine.set_calibration(wl['P'])
+    with pytest.raises(P2sError):
+        engine.triangulate(wl['xyl'], engine.tri_params(15.0, 0.3, 0))          # min_cameras < 1
+    with pytest.raises(P2sError):
+        engine.triangulate(wl['xyl'], engine.tri_params(15.0, 0.3, 2, undistort=True))   # no K/dist given
+    with pytest.raises(P2sError):
+        engine.triangulate(wl['xyl'], engine.tri_params(15.0, 0.3, 2, lr_swap=True))     # no swap_idx
+    with pytest.raises(P2sError):
+        engine.triangulate(wl['xyl'][:, :, :3], engine.tri_params(15.0, 0.3, 2))        # camera count mismatch
+
+
+def test_full_size_properties(engine):
+    """BASELINE config 2 size (8 cams x 26 kpts x 100k frames): properties that need no oracle run --
+    bit-identical repeat, frame-permutation equivariance, clean-data recovery of the generating 3D
+    points -- plus an oracle spot check on a random sample of frames."""
+    from oracle import triangulation_ref as tr
+    from pose2sim_amd import skeletons, synth
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    F, C, K = 100_000, 8, 26
+    wl = synth.make_config(F, C, K, 1, seed=2)
+    engine.set_calibration(wl['P'])
+    prm = engine.tri_params(15.0, 0.3, 2)
+    xyl = wl['xyl']
+    Q, err, nex, mask = engine.triangulate(xyl, prm)
+    Q2, err2, nex2, mask2 = engine.triangulate(xyl, prm)
+    assert np.array_equal(Q, Q2, equal_nan=True) and np.array_equal(err, err2, equal_nan=True)
+    assert np.array_equal(nex, nex2) and np.array_equal(mask, mask2)
+    perm = np.random.default_rng(0).permutation(F)
+    Qp, errp, nexp, maskp = engine.triangulate(xyl[perm], prm)
+    assert np.array_equal(Qp, Q[perm], equal_nan=True) and np.array_equal(maskp, mask[perm])
+    assert np.array_equal(nexp, nex[perm]) and np.array_equal(errp, err[perm], equal_nan=True)
+    # popcount(mask) == n_excl without L/R swap and zero likelihoods
+    pop = np.unpackbits(mask.view(np.uint8).reshape(-1, 4), axis=1).sum(axis=1).reshape(mask.shape)
+    assert np.array_equal(pop, nex)
+    # accepted units have error <= threshold and sit near the generating point (noise 1.5 px ~ cm)
+    ok = ~np.isnan(err)
+    assert ok.mean() > 0.99 and (err[ok] <= 15.0).all()
+    dist = np.linalg.norm(Q.reshape(F, K, 3) - wl['Q3d'].reshape(F, K, 3), axis=-1)[ok.reshape(F, K)]
+    assert np.median(dist) < 0.01 and np.percentile(dist, 99) < 0.05
+    # oracle spot check
+    sel = np.sort(np.random.default_rng(1).choice(F, 60, replace=False))
+    Qr, er, nr, mr = tr.triangulate_batch(xyl[sel], wl['P'], None, swap, 0.3, 15.0, 2)
+    _compare(Q[sel], err[sel], nex[sel], mask[sel], Qr, er, nr, mr, 'cfg2 sample')
+
+
+def test_noise_free_recovers_ground_truth(engine):
+    from pose2sim_amd import synth
+    wl = synth.make_config(500, 6, 26, 1, seed=9, noise_px=0.0, p_lowlik=0.0, p_outlier=0.0, p_missing_cam=0.0)
+    engine.set_calibration(wl['P'])
+    # float64 observations carry the exact projections
+    cams = wl['cams']
+    from pose2sim_amd import cvmath
+    xyl = wl['xyl'].astype(np.float64)
+    for c in range(6):
+        uv = cvmath.project_points(wl['Q3d'].reshape(-1, 3), cams['R_mat'][c], cams['T'][c], cams['K'][c], np.zeros(4))
+        xyl[:, 0, c, :, :2] = uv.reshape(500, 26, 2)
+    Q, err, nex, mask = engine.triangulate(xyl, engine.tri_params(15.0, 0.3, 2))
+    assert np.abs(Q.reshape(-1, 3) - wl['Q3d'].reshape(-1, 3)).max() < 1e-9
+    assert (nex == 0).all() and err.max() < 1e-6
