@@ -95,7 +95,7 @@ Geometry choose_geometry(int C, int K, int dtype) {
         const long lds = tile_al + extra;
         if (lds > 150 * 1024) break;
         const long units = (long)FB * K;
-        const int threads = (int)std::min<long>(1024, (units + 63) / 64 * 64);
+        const int threads = (int)std::min<long>(256, (units + 63) / 64 * 64);
         const long passes = (units + threads - 1) / threads;
         const double eff = (double)units / (double)(passes * threads);
         const int wg_per_cu = (int)std::min<long>(8, (160 * 1024) / lds);

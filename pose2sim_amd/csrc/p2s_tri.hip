@@ -6,15 +6,18 @@
 //
 //   stage    a tile of FB consecutive blocks ([FB][C][K][3], contiguous in HBM) is copied into LDS
 //            with 16-byte-per-lane coalesced loads; the C projection matrices sit beside it
-//   prepare  each lane undistorts (triangulation.py:808-813) and likelihood-masks (:817-821) the
-//            observations of its unit in place in LDS
+//   prepare  (undistort only) each lane undistorts the observations of its unit in place in LDS
+//            (triangulation.py:808-813); the likelihood mask (:817-821) is applied on the fly
 //   level 0  one lane per unit: weighted-DLT normal matrix (common.py:327-354 restated as the
-//            smallest eigenpair of A^T A, fp64), reprojection error (common.py:357-403)
+//            smallest eigenpair of A^T A, fp64), reprojection error (common.py:357-403);
+//            projection matrices come through the scalar cache (SGPR operands), loops are
+//            branch-free so that LDS reads of consecutive cameras overlap
 //   search   units whose error exceeds the threshold are handed to groups of G lanes of the same
 //            wavefront; lane j of a group evaluates camera subset #(round*G + j) of the level
 //            (lexicographic itertools.combinations order, triangulation.py:411), the group's
 //            argmin (first index on ties, :502) is taken with wave shuffles; levels proceed in
-//            lock step across the wave (ballot of units still above threshold)
+//            lock step across the wave (ballot of units still above threshold), and G is chosen
+//            per level to minimise passes x rounds
 //
 // Everything is data-parallel fp64 VALU work on an HBM-streamed tensor: no MFMA (4x4 systems).
 #include <hip/hip_runtime.h>
@@ -27,64 +30,92 @@ namespace {
 
 constexpr double kInf = __builtin_huge_val();
 
+// Calibration is read-only for the whole launch: going through the constant address space lets
+// every uniform-index access become a scalar (SMEM) load and the value an SGPR operand.
+typedef const __attribute__((address_space(4))) P2sCam *cam_cptr;
+
 __device__ __forceinline__ double d_nan() { return __builtin_nan(""); }
 
+// 1/d to ~1 ulp: v_rcp_f64 seed + two Newton steps (the IEEE division sequence costs about
+// twice as much).  0 -> inf, inf -> 0 and NaN pass through the seed unchanged.
+__device__ __forceinline__ double fast_rcp(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r0, 1.0);
+    double r = fma(r0, e, r0);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    return (e == e) ? r : r0;
+}
+
+// sqrt(s), s >= 0, to ~1 ulp: v_rsq_f64 seed, one Goldschmidt step, one residual correction.
+__device__ __forceinline__ double fast_sqrt(double s) {
+    const double y = __builtin_amdgcn_rsq(s);
+    double g = s * y;
+    double h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, s);
+    g = fma(d, h, g);
+    return (s == 0.0 || s == kInf) ? s : g;
+}
+
 // --------------------------------------------------------------------------------------------
-// Normal-matrix contribution of one camera: rows (P0 - x P2) w and (P1 - y P2) w.
-// N is the upper triangle of the 4x4 A^T A: [00 01 02 03 11 12 13 22 23 33].
-template <bool SUBTRACT>
-__device__ __forceinline__ void accum_camera(double N[10], const double *__restrict__ P, double x, double y,
-                                             double w) {
-    const double a0 = (P[0] - x * P[8]) * w, a1 = (P[1] - x * P[9]) * w, a2 = (P[2] - x * P[10]) * w,
-                 a3 = (P[3] - x * P[11]) * w;
-    const double b0 = (P[4] - y * P[8]) * w, b1 = (P[5] - y * P[9]) * w, b2 = (P[6] - y * P[10]) * w,
-                 b3 = (P[7] - y * P[11]) * w;
-    const double s = SUBTRACT ? -1.0 : 1.0;
-    N[0] += s * (a0 * a0 + b0 * b0);
-    N[1] += s * (a0 * a1 + b0 * b1);
-    N[2] += s * (a0 * a2 + b0 * b2);
-    N[3] += s * (a0 * a3 + b0 * b3);
-    N[4] += s * (a1 * a1 + b1 * b1);
-    N[5] += s * (a1 * a2 + b1 * b2);
-    N[6] += s * (a1 * a3 + b1 * b3);
-    N[7] += s * (a2 * a2 + b2 * b2);
-    N[8] += s * (a2 * a3 + b2 * b3);
-    N[9] += s * (a3 * a3 + b3 * b3);
+// Normal-matrix contribution of one camera: rows (P0 - x P2) w and (P1 - y P2) w
+// (common.py:344-345).  N is the upper triangle of the 4x4 A^T A: [00 01 02 03 11 12 13 22 23 33].
+// PT is either an SGPR-backed constant pointer or an LDS pointer.  SIGN = -1 removes a camera.
+template <int SIGN, typename PT>
+__device__ __forceinline__ void accum_camera(double N[10], PT P, double x, double y, double w) {
+    const double xw = x * w, yw = y * w;
+    const double a0 = fma(-xw, P[8], P[0] * w), a1 = fma(-xw, P[9], P[1] * w), a2 = fma(-xw, P[10], P[2] * w),
+                 a3 = fma(-xw, P[11], P[3] * w);
+    const double b0 = fma(-yw, P[8], P[4] * w), b1 = fma(-yw, P[9], P[5] * w), b2 = fma(-yw, P[10], P[6] * w),
+                 b3 = fma(-yw, P[11], P[7] * w);
+    const double s0 = SIGN * a0, s1 = SIGN * a1, s2 = SIGN * a2, s3 = SIGN * a3;
+    const double t0 = SIGN * b0, t1 = SIGN * b1, t2 = SIGN * b2, t3 = SIGN * b3;
+    N[0] = fma(s0, a0, fma(t0, b0, N[0]));
+    N[1] = fma(s0, a1, fma(t0, b1, N[1]));
+    N[2] = fma(s0, a2, fma(t0, b2, N[2]));
+    N[3] = fma(s0, a3, fma(t0, b3, N[3]));
+    N[4] = fma(s1, a1, fma(t1, b1, N[4]));
+    N[5] = fma(s1, a2, fma(t1, b2, N[5]));
+    N[6] = fma(s1, a3, fma(t1, b3, N[6]));
+    N[7] = fma(s2, a2, fma(t2, b2, N[7]));
+    N[8] = fma(s2, a3, fma(t2, b3, N[8]));
+    N[9] = fma(s3, a3, fma(t3, b3, N[9]));
 }
 
 // Smallest eigenvector of the 4x4 SPD matrix N, dehomogenised: v = (q, 1), N v = lambda v.
 // With N = [[M, b], [b^T, c]]: (M - lambda I) q = -b and lambda = c + b.q.  Newton on that secular
 // equation (== Rayleigh-quotient update) from lambda = 0, i.e. from the inhomogeneous least-squares
 // point; monotone and quadratically convergent below the smallest eigenvalue of M.  The 3x3
-// systems are solved by LDL^T.  Returns q = V[0:3,3]/V[3,3] of the reference's SVD
-// (common.py:348-350) to ~1e-12 relative.
+// systems are solved through the adjugate (one reciprocal).  Returns q = V[0:3,3]/V[3,3] of the
+// reference's SVD (common.py:348-350) to ~1e-12 relative.
 __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3]) {
     const double b0 = N[3], b1 = N[6], b2 = N[8], c = N[9];
+    const double m01 = N[1], m02 = N[2], m12 = N[5];
     const double tol_abs = 2e-15 * fabs(c);
     double lam = 0.0;
     double q0 = 0, q1 = 0, q2 = 0;
     bool done = false;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
-        const double d0 = N[0] - lam;
-        const double i0 = 1.0 / d0;
-        const double l10 = N[1] * i0, l20 = N[2] * i0;
-        const double d1 = (N[4] - lam) - l10 * N[1];
-        const double i1 = 1.0 / d1;
-        const double t21 = N[5] - l20 * N[1];
-        const double l21 = t21 * i1;
-        const double d2 = (N[7] - lam) - l20 * N[2] - l21 * t21;
-        const double i2 = 1.0 / d2;
-        const double z0 = -b0;
-        const double z1 = -b1 - l10 * z0;
-        const double z2 = -b2 - l20 * z0 - l21 * z1;
-        const double y2 = z2 * i2;
-        const double y1 = z1 * i1 - l21 * y2;
-        const double y0 = z0 * i0 - l10 * y1 - l20 * y2;
+        const double m00 = N[0] - lam, m11 = N[4] - lam, m22 = N[7] - lam;
+        const double c00 = fma(m11, m22, -m12 * m12);
+        const double c01 = fma(m02, m12, -m01 * m22);
+        const double c02 = fma(m01, m12, -m02 * m11);
+        const double c11 = fma(m00, m22, -m02 * m02);
+        const double c12 = fma(m01, m02, -m00 * m12);
+        const double c22 = fma(m00, m11, -m01 * m01);
+        const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
+        const double nid = -fast_rcp(det);
+        const double y0 = (c00 * b0 + c01 * b1 + c02 * b2) * nid;
+        const double y1 = (c01 * b0 + c11 * b1 + c12 * b2) * nid;
+        const double y2 = (c02 * b0 + c12 * b1 + c22 * b2) * nid;
         if (!done) { q0 = y0; q1 = y1; q2 = y2; }
         const double g = c + (b0 * y0 + b1 * y1 + b2 * y2) - lam;
         const double qq = 1.0 + (y0 * y0 + y1 * y1 + y2 * y2);
-        const double lam_new = lam + g / qq;
+        const double lam_new = fma(g, fast_rcp(qq), lam);
         const bool conv = fabs(lam_new - lam) <= 1e-9 * fabs(lam_new) + tol_abs;
         if (!done) lam = lam_new;
         // a NaN system never converges; give up on it at once
@@ -100,45 +131,46 @@ __device__ __forceinline__ double pair_distance(double dx, double dy) {
     const bool nx = !(dx == dx), ny = !(dy == dy);
     const double sx = nx ? 0.0 : dx * dx;
     const double sy = ny ? 0.0 : dy * dy;
-    return (nx && ny) ? kInf : sqrt(sx + sy);
+    return (nx && ny) ? kInf : fast_sqrt(sx + sy);
 }
 
-// reprojection (common.py:357-375)
-__device__ __forceinline__ void project_pinhole(const double *__restrict__ P, const double q[3], double &u,
-                                                double &v) {
-    const double a = P[0] * q[0] + P[1] * q[1] + P[2] * q[2] + P[3];
-    const double b = P[4] * q[0] + P[5] * q[1] + P[6] * q[2] + P[7];
-    const double z = P[8] * q[0] + P[9] * q[1] + P[10] * q[2] + P[11];
-    u = a / z;
-    v = b / z;
+// reprojection (common.py:357-375); P through the scalar cache
+__device__ __forceinline__ void project_pinhole(cam_cptr cam, const double q[3], double &u, double &v) {
+    const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
+    const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], fma(cam->P[6], q[2], cam->P[7])));
+    const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], fma(cam->P[10], q[2], cam->P[11])));
+    const double rz = fast_rcp(z);
+    u = a * rz;
+    v = b * rz;
 }
 
 // cv2.projectPoints with the ORIGINAL intrinsics and distortion (triangulation.py:473, quirk Q4).
-__device__ __forceinline__ void project_distorted(const P2sCam &cam, const double q[3], double &u, double &v) {
-    const double X = cam.R[0] * q[0] + cam.R[1] * q[1] + cam.R[2] * q[2] + cam.T[0];
-    const double Y = cam.R[3] * q[0] + cam.R[4] * q[1] + cam.R[5] * q[2] + cam.T[1];
-    double Z = cam.R[6] * q[0] + cam.R[7] * q[1] + cam.R[8] * q[2] + cam.T[2];
+__device__ __forceinline__ void project_distorted(cam_cptr cam, const double q[3], double &u, double &v) {
+    const double X = fma(cam->R[0], q[0], fma(cam->R[1], q[1], fma(cam->R[2], q[2], cam->T[0])));
+    const double Y = fma(cam->R[3], q[0], fma(cam->R[4], q[1], fma(cam->R[5], q[2], cam->T[1])));
+    double Z = fma(cam->R[6], q[0], fma(cam->R[7], q[1], fma(cam->R[8], q[2], cam->T[2])));
     Z = (Z == 0.0) ? 1.0 : Z;
-    const double x = X / Z, y = Y / Z;
+    const double rZ = fast_rcp(Z);
+    const double x = X * rZ, y = Y * rZ;
     const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
     const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-    const double cdist = 1 + cam.k[0] * r2 + cam.k[1] * r4 + cam.k[4] * r6;
-    const double xd = x * cdist + cam.k[2] * a1 + cam.k[3] * a2;
-    const double yd = y * cdist + cam.k[2] * a3 + cam.k[3] * a1;
-    u = xd * cam.fx + cam.cx;
-    v = yd * cam.fy + cam.cy;
+    const double cdist = 1 + cam->k[0] * r2 + cam->k[1] * r4 + cam->k[4] * r6;
+    const double xd = x * cdist + cam->k[2] * a1 + cam->k[3] * a2;
+    const double yd = y * cdist + cam->k[2] * a3 + cam->k[3] * a1;
+    u = xd * cam->fx + cam->cx;
+    v = yd * cam->fy + cam->cy;
 }
 
 // cv2.undistortPoints(float32 pts, K, dist, None, optim_K) (triangulation.py:810-813): 5 fixed-point
 // iterations in double, result rounded to float32.  Contraction is off and the operation order is
 // that of pose2sim_amd/cvmath.py so that the float32 rounding is bit-identical to the oracle's.
-__device__ __noinline__ void undistort_point(const P2sCam &cam, double &px, double &py) {
+__device__ __noinline__ void undistort_point(cam_cptr cam, double &px, double &py) {
 #pragma clang fp contract(off)
     const double u = (double)(float)px, v = (double)(float)py;
-    const double x0 = (u - cam.cx) * cam.ifx;
-    const double y0 = (v - cam.cy) * cam.ify;
+    const double x0 = (u - cam->cx) * cam->ifx;
+    const double y0 = (v - cam->cy) * cam->ify;
     double x = x0, y = y0;
-    const double k0 = cam.k[0], k1 = cam.k[1], k2 = cam.k[2], k3 = cam.k[3], k4 = cam.k[4];
+    const double k0 = cam->k[0], k1 = cam->k[1], k2 = cam->k[2], k3 = cam->k[3], k4 = cam->k[4];
     for (int j = 0; j < 5; ++j) {
         const double r2 = x * x + y * y;
         const double icdist = 1.0 / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
@@ -148,9 +180,9 @@ __device__ __noinline__ void undistort_point(const P2sCam &cam, double &px, doub
         x = (x0 - dx) * icdist;
         y = (y0 - dy) * icdist;
     }
-    const double xx = cam.nk[0] * x + cam.nk[1] * y + cam.nk[2];
-    const double yy = cam.nk[3] * x + cam.nk[4] * y + cam.nk[5];
-    const double ww = 1.0 / (cam.nk[6] * x + cam.nk[7] * y + cam.nk[8]);
+    const double xx = cam->nk[0] * x + cam->nk[1] * y + cam->nk[2];
+    const double yy = cam->nk[3] * x + cam->nk[4] * y + cam->nk[5];
+    const double ww = 1.0 / (cam->nk[6] * x + cam->nk[7] * y + cam->nk[8]);
     px = (double)(float)(xx * ww);
     py = (double)(float)(yy * ww);
 }
@@ -173,7 +205,7 @@ __device__ __forceinline__ uint32_t unrank_subset(uint32_t r, int n, int k, cons
     return S;
 }
 
-// Index of the n-th (0-based) set bit of a wave-uniform 64-bit mask, or -1.
+// Index of the n-th (0-based) set bit of a 64-bit mask, or -1.
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
     for (int i = 0; i < n; ++i) m &= m - 1;
     return m ? __builtin_ctzll(m) : -1;
@@ -181,31 +213,95 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 
-struct Cand {   // one evaluated camera configuration
-    double err;
-    double q[3];
+// One unit's observations in the LDS tile: camera c at p[c * stride + {0,1,2}].
+// The likelihood mask (triangulation.py:817-821) is applied while reading: a likelihood below the
+// threshold turns x, y and the likelihood into NaN (a NaN likelihood compares false and stays).
+template <typename T>
+struct UnitObs {
+    const T *p;
+    int stride;
+    double lik_thr;
+    __device__ __forceinline__ void raw(int c, double &x, double &y, double &w) const {
+        const T *q = p + c * stride;
+        x = (double)q[0]; y = (double)q[1]; w = (double)q[2];
+    }
+    __device__ __forceinline__ void masked_xy(int c, double &x, double &y) const {
+        double w;
+        raw(c, x, y, w);
+        const bool low = w < lik_thr;
+        x = low ? d_nan() : x;
+        y = low ? d_nan() : y;
+    }
 };
 
-// Mean reprojection error of point q over the cameras in `kept` (bit mask), at most `limit`
-// of them in camera order (limit = all for the plain candidate, M for the swap candidate).
-template <typename T, bool UNDISTORT>
-__device__ __forceinline__ double mean_reproj_error(const P2sTriArgs &a, const double *__restrict__ sP,
-                                                    const T *__restrict__ obs, int strideC, uint32_t kept,
-                                                    int limit, const double q[3], const T *__restrict__ obs_sw,
-                                                    int n_swapped) {
-    double sum = 0.0;
-    int taken = 0;
-    for (int c = 0; c < a.C; ++c) {
-        if (!((kept >> c) & 1u) || taken >= limit) continue;
-        double x = (double)obs[c * strideC + 0], y = (double)obs[c * strideC + 1];
-        if (taken < n_swapped) { x = (double)obs_sw[c * strideC + 0]; y = (double)obs_sw[c * strideC + 1]; }
-        double u, v;
-        if (UNDISTORT) project_distorted(a.cams[c], q, u, v);
-        else project_pinhole(sP + c * 12, q, u, v);
-        sum += pair_distance(u - x, v - y);
-        ++taken;
+// Level-0 pass over all cameras: classify each camera (NaN / zero likelihood) and accumulate the
+// normal matrix of the valid ones.  Branch-free: an invalid camera enters with weight 0.
+template <typename T>
+__device__ __forceinline__ void classify_and_accumulate(cam_cptr cams, int C, const UnitObs<T> &o, double N[10],
+                                                         uint32_t &nanmask, uint32_t &zeromask) {
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        double x, y, w;
+        o.raw(c, x, y, w);
+        const bool isn = !(w == w) || (w < o.lik_thr);
+        const bool isz = (w == 0.0) && !isn;
+        nanmask |= isn ? (1u << c) : 0u;
+        zeromask |= isz ? (1u << c) : 0u;
+        const bool ok = !(isn || isz);
+        accum_camera<1>(N, cams[c].P, ok ? x : 0.0, ok ? y : 0.0, ok ? w : 0.0);
     }
-    return sum / (double)taken;   // taken == 0 -> NaN, as np.mean of an empty list
+}
+
+// Mean reprojection error over the cameras of `kept` (triangulation.py:472-489).
+template <typename T, bool UNDISTORT>
+__device__ __forceinline__ double mean_error(cam_cptr cams, int C, const UnitObs<T> &o, uint32_t kept,
+                                             const double q[3]) {
+    double sum = 0.0;
+#pragma unroll 2
+    for (int c = 0; c < C; ++c) {
+        double x, y, w, u, v;
+        o.raw(c, x, y, w);
+        if (UNDISTORT) project_distorted(cams + c, q, u, v);
+        else project_pinhole(cams + c, q, u, v);
+        const double d = pair_distance(u - x, v - y);
+        sum += ((kept >> c) & 1u) ? d : 0.0;
+    }
+    return sum * fast_rcp((double)__popc(kept));   // no camera kept -> NaN, as np.mean([])
+}
+
+// L/R-swap candidate (triangulation.py:509-561, quirk Q3): the first M kept cameras carry the
+// mirrored keypoint's (x, y), still weighted by the unit's own likelihoods; the error is the mean
+// over those first M cameras only.
+template <typename T, bool UNDISTORT>
+__device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const UnitObs<T> &o, const UnitObs<T> &osw,
+                                                 uint32_t kept, int M, double qs[3]) {
+    double Nw[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Nw[i] = 0.0;
+    int taken = 0;
+    for (int c = 0; c < C; ++c) {
+        double x, y, w, xs, ys;
+        o.raw(c, x, y, w);
+        osw.masked_xy(c, xs, ys);
+        const bool k = (kept >> c) & 1u;
+        const bool sw = taken < M;
+        accum_camera<1>(Nw, cams[c].P, k ? (sw ? xs : x) : 0.0, k ? (sw ? ys : y) : 0.0, k ? w : 0.0);
+        taken += k ? 1 : 0;
+    }
+    smallest_eigvec(Nw, qs);
+    double sum = 0.0;
+    taken = 0;
+    for (int c = 0; c < C; ++c) {
+        double xs, ys, u, v;
+        osw.masked_xy(c, xs, ys);
+        if (UNDISTORT) project_distorted(cams + c, qs, u, v);
+        else project_pinhole(cams + c, qs, u, v);
+        const double d = pair_distance(u - xs, v - ys);
+        const bool k = ((kept >> c) & 1u) && taken < M;
+        sum += k ? d : 0.0;
+        taken += ((kept >> c) & 1u) ? 1 : 0;
+    }
+    return sum * fast_rcp((double)M);
 }
 
 }  // namespace
@@ -213,13 +309,15 @@ __device__ __forceinline__ double mean_reproj_error(const P2sTriArgs &a, const d
 // ---------------------------------------------------------------------------------------------
 // LDS layout: [tile: FB*C*K*3 of T][P: C*12 doubles][binom: 33*33 u32]
 template <typename T, bool UNDISTORT, bool LRSWAP>
-__global__ void p2s_tri_kernel(const P2sTriArgs a) {
+__global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = a.C, K = a.K, FB = a.FB;
     const int blk_elems = C * K * 3;
+    const int strideC = K * 3;
     T *tile = reinterpret_cast<T *>(smem);
     double *sP = reinterpret_cast<double *>(smem + a.lds_P_off);
     uint32_t *sBinom = reinterpret_cast<uint32_t *>(smem + a.lds_binom_off);
+    cam_cptr cams = (cam_cptr)a.cams;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -243,88 +341,69 @@ __global__ void p2s_tri_kernel(const P2sTriArgs a) {
     }
     __syncthreads();
 
-    // ---- prepare: undistort + likelihood mask, in place ------------------------------------
-    for (int u = tid; u < n_units; u += blockDim.x) {
-        const int b = u / K, k = u - b * K;
-        T *o = tile + (size_t)b * blk_elems + k * 3;
-        for (int c = 0; c < C; ++c) {
-            T *p = o + c * K * 3;
-            double x = (double)p[0], y = (double)p[1];
-            const double l = (double)p[2];
-            if (UNDISTORT) {
-                undistort_point(a.cams[c], x, y);
+    // ---- prepare: undistort in place (the mirrored keypoint of another lane reads it too) ----
+    if (UNDISTORT) {
+        for (int u = tid; u < n_units; u += blockDim.x) {
+            const int b = u / K, k = u - b * K;
+            T *o = tile + (size_t)b * blk_elems + k * 3;
+            for (int c = 0; c < C; ++c) {
+                T *p = o + c * strideC;
+                double x = (double)p[0], y = (double)p[1];
+                undistort_point(cams + c, x, y);
                 p[0] = (T)x; p[1] = (T)y;
             }
-            if (l < a.lik_thr) {           // NaN likelihood compares false and stays NaN
-                p[0] = (T)d_nan(); p[1] = (T)d_nan(); p[2] = (T)d_nan();
-            }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
     const double thr = a.thr;
-    const int G = a.G;                      // lanes per search group (power of two >= C, <= 64)
-    const int groups = 64 / G;
-    const int grp = lane / G, lig = lane - grp * G;
+    const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
 
     for (int base = 0; base < n_units; base += blockDim.x) {
+        if (base + (tid & ~63) >= n_units) break;                  // whole wave past the tile
         const int u = base + tid;
         const bool active = u < n_units;
         const int b = active ? u / K : 0, k = active ? u - b * K : 0;
-        const T *obs = tile + (size_t)b * blk_elems + k * 3;            // camera stride K*3
-        const int strideC = K * 3;
-        const T *obs_sw = obs;
-        if (LRSWAP) obs_sw = tile + (size_t)b * blk_elems + a.swap_idx[k] * 3;
+        UnitObs<T> obs{tile + (size_t)b * blk_elems + k * 3, strideC, a.lik_thr};
+        UnitObs<T> obs_sw = obs;
+        if (LRSWAP) obs_sw.p = tile + (size_t)b * blk_elems + a.swap_idx[k] * 3;
 
         // ---- level 0 ---------------------------------------------------------------------
         double N[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) N[i] = 0.0;
         uint32_t nanmask = 0, zeromask = 0;
-        if (active) {
-            for (int c = 0; c < C; ++c) {
-                const double x = (double)obs[c * strideC + 0], y = (double)obs[c * strideC + 1],
-                             w = (double)obs[c * strideC + 2];
-                if (!(w == w)) { nanmask |= 1u << c; continue; }
-                if (w == 0.0) { zeromask |= 1u << c; continue; }
-                accum_camera<false>(N, sP + c * 12, x, y, w);
-            }
-        }
-        const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+        classify_and_accumulate<T>(cams, C, obs, N, nanmask, zeromask);
         const uint32_t dmask = nanmask | zeromask;                 // cameras already out (NaN or zero likelihood)
         const uint32_t valid = allmask & ~dmask;
         const int V = __popc(dmask);
         const int nvalid = C - V;
-        const int Lmax = C - a.min_cams - V;                       // last level that runs (triangulation.py:408, 437-441)
+        const int Lmax = active ? C - a.min_cams - V : -1;         // last level that runs (triangulation.py:408, 437-441)
 
         double err_min = kInf;
         double Qb[3] = {d_nan(), d_nan(), d_nan()};
         int n_excl = C;                                            // :595-596 when no level completes
         uint32_t mask = allmask;
         bool need = false;
-
-        if (active && Lmax >= 0) {
-            double q[3] = {d_nan(), d_nan(), d_nan()};
-            if (nvalid >= 2) smallest_eigvec(N, q);                // common.py:347 (fewer than 4 rows -> NaN)
-            double e = mean_reproj_error<T, UNDISTORT>(a, sP, obs, strideC, valid, C, q, obs, 0);
-            err_min = e; Qb[0] = q[0]; Qb[1] = q[1]; Qb[2] = q[2];
-            n_excl = V; mask = nanmask;
-            if (LRSWAP && err_min > thr && nvalid > 2) {           // :509-579 at level 0: M = nvalid
-                double Ns[10];
-#pragma unroll
-                for (int i = 0; i < 10; ++i) Ns[i] = 0.0;
-                for (int c = 0; c < C; ++c) {
-                    if (!((valid >> c) & 1u)) continue;
-                    accum_camera<false>(Ns, sP + c * 12, (double)obs_sw[c * strideC + 0],
-                                        (double)obs_sw[c * strideC + 1], (double)obs[c * strideC + 2]);
-                }
-                double qs[3];
-                smallest_eigvec(Ns, qs);
-                const double es = mean_reproj_error<T, UNDISTORT>(a, sP, obs, strideC, valid, nvalid, qs, obs_sw, nvalid);
-                if (es < err_min) { err_min = es; Qb[0] = qs[0]; Qb[1] = qs[1]; Qb[2] = qs[2]; }
+        {
+            double q[3];
+            smallest_eigvec(N, q);
+            if (nvalid < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }   // common.py:347: fewer than 4 rows
+            const double e = mean_error<T, UNDISTORT>(cams, C, obs, valid, q);
+            if (Lmax >= 0) {
+                err_min = e; Qb[0] = q[0]; Qb[1] = q[1]; Qb[2] = q[2];
+                n_excl = V; mask = nanmask;
             }
-            need = (err_min > thr) && (Lmax >= 1);
         }
+        if (LRSWAP) {                                              // :509-579 at level 0: M = nvalid
+            const bool want = (Lmax >= 0) && (err_min > thr) && (nvalid > 2);
+            if (__any(want)) {
+                double qs[3];
+                const double es = swap_candidate<T, UNDISTORT>(cams, C, obs, obs_sw, valid, nvalid, qs);
+                if (want && es < err_min) { err_min = es; Qb[0] = qs[0]; Qb[1] = qs[1]; Qb[2] = qs[2]; }
+            }
+        }
+        need = (Lmax >= 1) && (err_min > thr);
 
         // ---- subset search, levels in lock step across the wave -----------------------------
         unsigned long long pend_level = __ballot(need);
@@ -332,6 +411,22 @@ __global__ void p2s_tri_kernel(const P2sTriArgs a) {
             unsigned long long pending = pend_level;
             bool cont = false;                                      // owner lanes: continue to level+1
             const uint32_t nsub = sBinom[C * 33 + level];
+            // lanes per unit for this level: the power of two that needs the fewest
+            // (passes over the pending units) x (rounds over the level's subsets)
+            int lg = 2;
+            {
+                const uint32_t npend = (uint32_t)__popcll(pend_level);
+                uint32_t best_cost = 0xffffffffu;
+                for (int l = 2; l <= 6; ++l) {
+                    const uint32_t passes = ((npend << l) + 63u) >> 6;
+                    const uint32_t rounds = (nsub + (1u << l) - 1u) >> l;
+                    const uint32_t cost = passes * rounds;
+                    if (cost <= best_cost) { best_cost = cost; lg = l; }
+                }
+            }
+            const int G = 1 << lg, groups = 64 >> lg;
+            const int grp = lane >> lg, lig = lane & (G - 1);
+
             while (pending != 0ull) {
                 const unsigned long long before = pending;
                 for (int i = 0; i < groups && pending; ++i) pending &= pending - 1;
@@ -341,16 +436,17 @@ __global__ void p2s_tri_kernel(const P2sTriArgs a) {
                 // gather the owner's state
                 const int src = owner < 0 ? lane : owner;
                 const uint32_t o_nan = __shfl(nanmask, src, 64), o_zero = __shfl(zeromask, src, 64);
-                const int o_unit = __shfl(u, src, 64);
+                const int o_unit_raw = __shfl(u, src, 64);
+                const int o_unit = owner < 0 ? 0 : o_unit_raw;
                 double No[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) No[i] = shfl_d(N[i], src);
                 const uint32_t o_d = o_nan | o_zero, o_valid = allmask & ~o_d;
                 const int oV = __popc(o_d);
                 const int ob = o_unit / K, ok = o_unit - ob * K;
-                const T *oobs = tile + (size_t)ob * blk_elems + ok * 3;
-                const T *oobs_sw = oobs;
-                if (LRSWAP) oobs_sw = tile + (size_t)ob * blk_elems + a.swap_idx[ok] * 3;
+                UnitObs<T> oobs{tile + (size_t)ob * blk_elems + ok * 3, strideC, a.lik_thr};
+                UnitObs<T> oobs_sw = oobs;
+                if (LRSWAP) oobs_sw.p = tile + (size_t)ob * blk_elems + a.swap_idx[ok] * 3;
                 const int M = C - oV - level;                       // cameras left when `level` valid ones go (:437, 513)
 
                 // best candidates seen by this lane (plain / swap), lowest rank first
@@ -373,39 +469,29 @@ __global__ void p2s_tri_kernel(const P2sTriArgs a) {
                         for (int i = 0; i < np; ++i) { low |= dd & (0u - dd); dd &= dd - 1; }
                         go = (pad == low);
                     }
-                    if (!go) continue;
+                    if (!__any(go)) continue;
                     const uint32_t Rreal = S & o_valid;
                     const uint32_t kept = o_valid & ~Rreal;
                     const int nkept = __popc(kept);
                     double Ns[10];
 #pragma unroll
                     for (int i = 0; i < 10; ++i) Ns[i] = No[i];
-                    for (uint32_t rr = Rreal; rr; rr &= rr - 1) {
-                        const int c = __builtin_ctz(rr);
-                        accum_camera<true>(Ns, sP + c * 12, (double)oobs[c * strideC + 0],
-                                           (double)oobs[c * strideC + 1], (double)oobs[c * strideC + 2]);
+                    for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                        const int c = rr ? __builtin_ctz(rr) : 0;
+                        double x, y, w;
+                        oobs.raw(c, x, y, w);
+                        const bool on = rr != 0u;
+                        accum_camera<-1>(Ns, sP + c * 12, on ? x : 0.0, on ? y : 0.0, on ? w : 0.0);
                     }
-                    double q[3] = {d_nan(), d_nan(), d_nan()};
-                    if (nkept >= 2) smallest_eigvec(Ns, q);
-                    const double e = mean_reproj_error<T, UNDISTORT>(a, sP, oobs, strideC, kept, C, q, oobs, 0);
-                    if (e < be || (brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
+                    double q[3];
+                    smallest_eigvec(Ns, q);
+                    if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
+                    const double e = mean_error<T, UNDISTORT>(cams, C, oobs, kept, q);
+                    if (go && (e < be || brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
                     if (LRSWAP && M > 2) {
-                        // the first M kept cameras carry the mirrored keypoint (quirk Q3)
-                        double Nw[10];
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) Nw[i] = 0.0;
-                        int taken = 0;
-                        for (int c = 0; c < C; ++c) {
-                            if (!((kept >> c) & 1u)) continue;
-                            const T *p = (taken < M) ? oobs_sw : oobs;
-                            accum_camera<false>(Nw, sP + c * 12, (double)p[c * strideC + 0],
-                                                (double)p[c * strideC + 1], (double)oobs[c * strideC + 2]);
-                            ++taken;
-                        }
                         double qs[3];
-                        smallest_eigvec(Nw, qs);
-                        const double es = mean_reproj_error<T, UNDISTORT>(a, sP, oobs, strideC, kept, M, qs, oobs_sw, M);
-                        if (es < se || (srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
+                        const double es = swap_candidate<T, UNDISTORT>(cams, C, oobs, oobs_sw, kept, M, qs);
+                        if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
                     }
                 }
 
