@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2s_hip.so')
+LIB_PATH = os.environ.get('P2S_LIB') or os.path.join(_HERE, 'csrc', 'libp2s_hip.so')   # P2S_LIB: kernel experiments only
 
 P2S_F32, P2S_F64 = 0, 1
 P2S_MAX_CAMS = 32

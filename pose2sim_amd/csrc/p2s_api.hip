@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -69,30 +70,30 @@ struct p2s_ctx {
     bool full_calib = false;     // K, dist, R, T, newK were provided
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Scratch in, swap, q, err, nexcl, mask, aux0, aux1;
+    Scratch wl_rec, wl_count;
 };
 
 namespace {
 
 struct Geometry {
-    int FB, threads, lds_bytes, lds_P_off, lds_binom_off, G;
+    int FB, threads, lds_bytes;
 };
 
 int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 
-// Tile geometry: FB consecutive (frame, person) blocks per workgroup.  The tile start must stay
-// 16-byte aligned for the dwordx4 staging loads, the lanes of a workgroup should be nearly all
-// busy (FB*K close to a multiple of 64), and several workgroups should fit the CU's 160 KB LDS.
+// Tile geometry of the streaming kernel: FB consecutive (frame, person) blocks per workgroup.
+// The tile start must stay 16-byte aligned for the dwordx4 staging loads, the lanes of a workgroup
+// should be nearly all busy (FB*K close to a multiple of 64), and several workgroups should fit
+// the CU's 160 KB LDS.
 Geometry choose_geometry(int C, int K, int dtype) {
     const int elem = dtype == P2S_F32 ? 4 : 8;
     const long blk_bytes = (long)C * K * 3 * elem;
     const int step = 16 / gcd_i(16, (int)(blk_bytes % 16 == 0 ? 16 : blk_bytes % 16));
-    const int extra = ((C * 12 * 8 + 15) / 16) * 16 + 33 * 33 * 4;
     Geometry best{};
     double best_score = -1.0;
     for (int FB = step; FB <= 4096; FB += step) {
         const long tile = FB * blk_bytes;
-        const long tile_al = (tile + 15) / 16 * 16;
-        const long lds = tile_al + extra;
+        const long lds = (tile + 15) / 16 * 16;
         if (lds > 150 * 1024) break;
         const long units = (long)FB * K;
         const int threads = (int)std::min<long>(256, (units + 63) / 64 * 64);
@@ -108,18 +109,13 @@ Geometry choose_geometry(int C, int K, int dtype) {
             best.FB = FB;
             best.threads = threads;
             best.lds_bytes = (int)lds;
-            best.lds_P_off = (int)tile_al;
-            best.lds_binom_off = (int)tile_al + ((C * 12 * 8 + 15) / 16) * 16;
         }
     }
-    if (best_score < 0) {   // a single block does not fit: not supported
-        best.FB = 0;
-    }
-    int G = 4;
-    while (G < C) G <<= 1;
-    best.G = G;
+    if (best_score < 0) best.FB = 0;   // a single block does not fit: not supported
     return best;
 }
+
+constexpr int64_t kChunkUnits = 1 << 21;   // units per (level-0, search) kernel pair: bounds the work-list scratch
 
 void fill_binom(uint32_t *b) {
     for (int n = 0; n < 33; ++n)
@@ -200,6 +196,7 @@ int p2s_destroy(p2s_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->in.release(); ctx->swap.release(); ctx->q.release(); ctx->err.release();
     ctx->nexcl.release(); ctx->mask.release(); ctx->aux0.release(); ctx->aux1.release();
+    ctx->wl_rec.release(); ctx->wl_count.release();
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->d_binom) (void)hipFree(ctx->d_binom);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -283,8 +280,33 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     const int C = ctx->n_cams;
     Geometry g = choose_geometry(C, n_kpts, dtype);
     if (g.FB == 0) return fail(P2S_ERR_INVALID_ARG, "one block of C=%d x K=%d does not fit in LDS", C, n_kpts);
-    const int64_t n_tiles = (n_blocks + g.FB - 1) / g.FB;
-    if (n_tiles > 0x7fffffffLL) return fail(P2S_ERR_INVALID_ARG, "too many tiles (%lld)", (long long)n_tiles);
+    const int elem = dtype == P2S_F32 ? 4 : 8;
+    const int rec_bytes = 8 + 3 * C * elem * (params->handle_lr_swap ? 2 : 1);
+
+    // chunks of whole tiles, at most kChunkUnits units each
+    int64_t chunk_blocks = std::max<int64_t>(g.FB, (kChunkUnits / n_kpts) / g.FB * g.FB);
+    chunk_blocks = std::min<int64_t>(chunk_blocks, (n_blocks + g.FB - 1) / g.FB * g.FB);
+    const int64_t n_chunks = (n_blocks + chunk_blocks - 1) / chunk_blocks;
+    const int64_t chunk_units = chunk_blocks * n_kpts;
+    if (chunk_units > 0xffffffffLL / 2) return fail(P2S_ERR_INVALID_ARG, "K=%d too large", n_kpts);
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    // the work list: P2S_WL_SHARDS shards, workgroup b of the streaming kernel appends to shard b % SHARDS;
+    // two lists are used alternately by consecutive chunks; counters are zeroed on the stream first
+    const int64_t tiles_per_chunk = chunk_blocks / g.FB;
+    const int64_t shard_cap = (tiles_per_chunk + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * (int64_t)g.FB * n_kpts;
+    const size_t list_bytes = (size_t)P2S_WL_SHARDS * shard_cap * rec_bytes;
+    if ((rc = ctx->wl_rec.ensure(2 * list_bytes)) != P2S_OK) return rc;
+    if ((rc = ctx->wl_count.ensure((size_t)n_chunks * P2S_WL_SHARDS * sizeof(uint32_t))) != P2S_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->wl_count.p, 0, (size_t)n_chunks * P2S_WL_SHARDS * sizeof(uint32_t), ctx->stream));
+
+    // search kernel geometry: LDS = [P][binom][waves x 64 records]
+    const int lds_binom_off = (C * 12 * 8 + 15) / 16 * 16;
+    const int lds_rec_off = (lds_binom_off + 33 * 33 * 4 + 15) / 16 * 16;
+    const int64_t fit = (40 * 1024) / (64 * (int64_t)rec_bytes);
+    const int wpb = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;   // waves per search workgroup
+    const int lds1 = lds_rec_off + wpb * 64 * rec_bytes;
+    if (lds1 > 160 * 1024) return fail(P2S_ERR_INVALID_ARG, "search records of C=%d do not fit in LDS", C);
 
     P2sTriArgs a{};
     a.xyl = d_xyl;
@@ -292,16 +314,36 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     a.Q = d_Q; a.err = d_err; a.n_excl = d_n_excl; a.mask = d_excl_mask;
     a.cams = ctx->d_cams;
     a.binom = ctx->d_binom;
-    a.n_blocks = n_blocks;
-    a.K = n_kpts; a.C = C; a.FB = g.FB; a.G = g.G;
-    a.lds_P_off = g.lds_P_off; a.lds_binom_off = g.lds_binom_off;
+    a.K = n_kpts; a.C = C; a.FB = g.FB;
+    a.rec_bytes = rec_bytes;
+    a.wl_capacity = (uint32_t)shard_cap;
+    a.lds_binom_off = lds_binom_off; a.lds_rec_off = lds_rec_off;
     a.min_cams = params->min_cameras;
     a.undistort = params->undistort_points ? 1 : 0;
     a.lr_swap = params->handle_lr_swap ? 1 : 0;
     a.thr = params->reproj_error_threshold;
     a.lik_thr = params->likelihood_threshold;
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(p2s_launch_tri(a, dtype, (int)n_tiles, g.threads, (size_t)g.lds_bytes, ctx->stream));
+    if (const char *dbg = getenv("P2S_DEBUG_MODE")) a.debug_mode = atoi(dbg);   // diagnostics only
+
+    for (int64_t ch = 0; ch < n_chunks; ++ch) {
+        a.block0 = ch * chunk_blocks;
+        a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - a.block0);
+        a.wl_count = (uint32_t *)ctx->wl_count.p + ch * P2S_WL_SHARDS;
+        a.wl_rec = (unsigned char *)ctx->wl_rec.p + (size_t)(ch & 1) * list_bytes;
+        P2sTriLaunch L{};
+        L.grid0 = (int)((a.n_blocks + g.FB - 1) / g.FB);
+        L.threads0 = g.threads;
+        L.lds0 = g.lds_bytes;
+        // persistent search grid: a multiple of P2S_WL_SHARDS waves, at most 4096, no more than the
+        // chunk could ever need
+        const int64_t need_waves = (a.n_blocks * n_kpts + 63) / 64 + P2S_WL_SHARDS;
+        int64_t waves = std::min<int64_t>(4096, (need_waves + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * P2S_WL_SHARDS);
+        while (waves % wpb) waves += P2S_WL_SHARDS;
+        L.grid1 = (int)(waves / wpb);
+        L.threads1 = 64 * wpb;
+        L.lds1 = lds1;
+        HIP_TRY(p2s_launch_tri(a, dtype, L, ctx->stream));
+    }
     return P2S_OK;
 }
 

@@ -18,20 +18,35 @@ struct P2sCam {
     double center[3];      // -R^T T                            (association rays)
 };
 
+// The work list is cut into shards (workgroup b appends to shard b % P2S_WL_SHARDS) so that the
+// append counters do not serialise: one returning atomic per wave on ONE word caps near 90 per us.
+#define P2S_WL_SHARDS 128
+
 struct P2sTriArgs {
-    const void *xyl;
+    const void *xyl;             // whole tensor [n_blocks_total][C][K][3]
     const int32_t *swap_idx;
     double *Q;
     float *err;
     uint8_t *n_excl;
     uint32_t *mask;
     const P2sCam *cams;
-    const uint32_t *binom;   // [33][33] binomial coefficients
-    int64_t n_blocks;
-    int32_t K, C, FB, G;
-    int32_t lds_P_off, lds_binom_off;
+    const uint32_t *binom;       // [33][33] binomial coefficients
+    uint32_t *wl_count;          // work list of this chunk: P2S_WL_SHARDS record counts (zeroed before kernel 1)
+    unsigned char *wl_rec;       // records: {u32 unit id in chunk, u32 pad, T obs[C][3] (, T obs_swapped[C][3])}
+    int64_t block0;              // first (frame, person) block of this chunk
+    int64_t n_blocks;            // blocks in this chunk
+    uint32_t wl_capacity;        // records per shard
+    int32_t rec_bytes;
+    int32_t K, C, FB;
+    int32_t lds_binom_off, lds_rec_off;   // kernel 2 LDS layout: [P][binom][records]
     int32_t min_cams, undistort, lr_swap;
+    int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
     double thr, lik_thr;
+};
+
+struct P2sTriLaunch {
+    int grid0, threads0, lds0;   // level-0 (streaming) kernel
+    int grid1, threads1, lds1;   // search kernel
 };
 
 struct P2sAssocArgs {
@@ -45,7 +60,7 @@ struct P2sAssocArgs {
     double recon_thr, min_affinity, w_rank, tol, w_sparse;
 };
 
-hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, int grid, int threads, size_t lds, hipStream_t s);
+hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s);
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s);
 
 #endif

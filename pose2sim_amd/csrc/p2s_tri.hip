@@ -307,27 +307,27 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const Uni
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-// LDS layout: [tile: FB*C*K*3 of T][P: C*12 doubles][binom: 33*33 u32]
+// Kernel 1 -- streaming pass.  LDS: [tile: FB*C*K*3 of T].
+// Every unit gets its level-0 result; units that must enter the camera-subset search append a
+// compact record (unit id + their C observations as seen after undistortion) to the work list.
 template <typename T, bool UNDISTORT, bool LRSWAP>
-__global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
+__global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int C = a.C, K = a.K, FB = a.FB;
     const int blk_elems = C * K * 3;
     const int strideC = K * 3;
     T *tile = reinterpret_cast<T *>(smem);
-    double *sP = reinterpret_cast<double *>(smem + a.lds_P_off);
-    uint32_t *sBinom = reinterpret_cast<uint32_t *>(smem + a.lds_binom_off);
     cam_cptr cams = (cam_cptr)a.cams;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int64_t tile0 = (int64_t)blockIdx.x * FB;               // first block of this tile
-    const int nb = (int)min((int64_t)FB, a.n_blocks - tile0);      // blocks in this tile
+    const int64_t tile0 = a.block0 + (int64_t)blockIdx.x * FB;     // first block of this tile
+    const int nb = (int)min((int64_t)FB, a.block0 + a.n_blocks - tile0);
     const int n_units = nb * K;
 
     // ---- stage ---------------------------------------------------------------------------
     {
-        const T *src = reinterpret_cast<const T *>(a.xyl) + tile0 * blk_elems;
+        const T *src = reinterpret_cast<const T *>(a.xyl) + (a.debug_mode == 2 ? 0 : tile0 * blk_elems);
         const int n_elems = nb * blk_elems;
         constexpr int VEC = 16 / sizeof(T);
         const int n_vec = n_elems / VEC;                           // tile base is 16-B aligned (host)
@@ -336,8 +336,6 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
         v4u *dst4 = reinterpret_cast<v4u *>(tile);
         for (int i = tid; i < n_vec; i += blockDim.x) dst4[i] = __builtin_nontemporal_load(src4 + i);
         for (int i = n_vec * VEC + tid; i < n_elems; i += blockDim.x) tile[i] = src[i];
-        for (int i = tid; i < C * 12; i += blockDim.x) sP[i] = a.cams[i / 12].P[i % 12];
-        for (int i = tid; i < 33 * 33; i += blockDim.x) sBinom[i] = a.binom[i];
     }
     __syncthreads();
 
@@ -359,6 +357,19 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
     const double thr = a.thr;
     const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
 
+    if (a.debug_mode == 1) {   // diagnostics: memory skeleton only
+        for (int u = tid; u < n_units; u += blockDim.x) {
+            const int b = u / K, k = u - b * K;
+            const T *o = tile + (size_t)b * blk_elems + k * 3;
+            double s = 0;
+            for (int c = 0; c < C; ++c) s += (double)o[c * strideC] + (double)o[c * strideC + 1] + (double)o[c * strideC + 2];
+            const int64_t gu = tile0 * K + u;
+            a.Q[gu * 3] = s; a.Q[gu * 3 + 1] = s; a.Q[gu * 3 + 2] = s;
+            a.err[gu] = (float)s; a.n_excl[gu] = 0; a.mask[gu] = 0;
+        }
+        return;
+    }
+
     for (int base = 0; base < n_units; base += blockDim.x) {
         if (base + (tid & ~63) >= n_units) break;                  // whole wave past the tile
         const int u = base + tid;
@@ -368,7 +379,6 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
         UnitObs<T> obs_sw = obs;
         if (LRSWAP) obs_sw.p = tile + (size_t)b * blk_elems + a.swap_idx[k] * 3;
 
-        // ---- level 0 ---------------------------------------------------------------------
         double N[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) N[i] = 0.0;
@@ -384,7 +394,6 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
         double Qb[3] = {d_nan(), d_nan(), d_nan()};
         int n_excl = C;                                            // :595-596 when no level completes
         uint32_t mask = allmask;
-        bool need = false;
         {
             double q[3];
             smallest_eigvec(N, q);
@@ -403,10 +412,116 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
                 if (want && es < err_min) { err_min = es; Qb[0] = qs[0]; Qb[1] = qs[1]; Qb[2] = qs[2]; }
             }
         }
-        need = (Lmax >= 1) && (err_min > thr);
+        const bool need = (Lmax >= 1) && (err_min > thr);          // goes on to level 1 (kernel 2)
+
+        // ---- level-0 result (triangulation.py:588-604); kernel 2 overwrites it for `need` units
+        if (active) {
+            const int64_t gu = tile0 * K + u;
+            const bool fail = !(err_min <= thr);
+            double *Qo = a.Q + gu * 3;
+            Qo[0] = fail ? d_nan() : Qb[0];
+            Qo[1] = fail ? d_nan() : Qb[1];
+            Qo[2] = fail ? d_nan() : Qb[2];
+            a.err[gu] = fail ? __builtin_nanf("") : (float)err_min;
+            a.n_excl[gu] = (uint8_t)n_excl;
+            a.mask[gu] = mask;
+        }
+
+        // ---- work list: one atomic per wave, records written by their lanes --------------------
+        const unsigned long long hard = __ballot(need);
+        if (hard != 0ull) {
+            uint32_t base_rec = 0;
+            const uint32_t shard = blockIdx.x % P2S_WL_SHARDS;
+            if (lane == 0) base_rec = atomicAdd(a.wl_count + shard, (uint32_t)__popcll(hard));
+            base_rec = __shfl(base_rec, 0, 64);
+            if (need) {
+                const uint32_t slot = base_rec + (uint32_t)__popcll(hard & ((1ull << lane) - 1ull));
+                unsigned char *rec = a.wl_rec + ((size_t)shard * a.wl_capacity + slot) * a.rec_bytes;
+                reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)(tile0 * K + u - a.block0 * K);   // unit id within the chunk
+                reinterpret_cast<uint32_t *>(rec)[1] = 0u;
+                T *ro = reinterpret_cast<T *>(rec + 8);
+                for (int c = 0; c < C; ++c) {
+                    ro[c * 3 + 0] = obs.p[c * strideC + 0];
+                    ro[c * 3 + 1] = obs.p[c * strideC + 1];
+                    ro[c * 3 + 2] = obs.p[c * strideC + 2];
+                }
+                if (LRSWAP) {
+                    T *rs = ro + C * 3;
+                    for (int c = 0; c < C; ++c) {
+                        rs[c * 3 + 0] = obs_sw.p[c * strideC + 0];
+                        rs[c * 3 + 1] = obs_sw.p[c * strideC + 1];
+                        rs[c * 3 + 2] = obs_sw.p[c * strideC + 2];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 2 -- camera-subset search over the work list.  One wave owns 64 records at a time
+// (lane i = record i); LDS: [P: C*12 doubles][binom: 33*33 u32][per wave: 64 records].
+// Persistent grid: waves stride over the list whose length kernel 1 left in *wl_count.
+template <typename T, bool UNDISTORT, bool LRSWAP>
+__global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = a.C;
+    double *sP = reinterpret_cast<double *>(smem);
+    uint32_t *sBinom = reinterpret_cast<uint32_t *>(smem + a.lds_binom_off);
+    cam_cptr cams = (cam_cptr)a.cams;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    unsigned char *recs = smem + a.lds_rec_off + (size_t)wave * 64 * a.rec_bytes;
+
+    for (int i = tid; i < C * 12; i += blockDim.x) sP[i] = a.cams[i / 12].P[i % 12];
+    for (int i = tid; i < 33 * 33; i += blockDim.x) sBinom[i] = a.binom[i];
+    __syncthreads();
+
+    // wave w works on shard w % SHARDS, taking every (waves / SHARDS)-th group of 64 records
+    const uint32_t gwave = blockIdx.x * waves_per_block + wave;
+    const uint32_t n_waves = gridDim.x * waves_per_block;          // a multiple of P2S_WL_SHARDS (host)
+    const uint32_t shard = gwave % P2S_WL_SHARDS;
+    const uint32_t count = min(a.wl_count[shard], a.wl_capacity);
+    const double thr = a.thr;
+    const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+    const uint32_t wave_stride = (n_waves / P2S_WL_SHARDS) * 64u;
+
+    for (uint32_t rec0 = (gwave / P2S_WL_SHARDS) * 64u; rec0 < count; rec0 += wave_stride) {
+        const int n = (int)min(64u, count - rec0);
+        // ---- this wave's records: contiguous copy into its LDS region ----------------------
+        {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.wl_rec + ((size_t)shard * a.wl_capacity + rec0) * a.rec_bytes);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(recs);
+            const int nw = n * (a.rec_bytes >> 2);
+            for (int i = lane; i < nw; i += 64) dst[i] = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const bool active = lane < n;
+        const unsigned char *myrec = recs + (size_t)(active ? lane : 0) * a.rec_bytes;
+        const uint32_t u = *reinterpret_cast<const uint32_t *>(myrec);          // unit id within the chunk
+        UnitObs<T> obs{reinterpret_cast<const T *>(myrec + 8), 3, a.lik_thr};
+
+        // level-0 state again (cheaper than carrying 80 bytes per unit through HBM)
+        double N[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) N[i] = 0.0;
+        uint32_t nanmask = 0, zeromask = 0;
+        classify_and_accumulate<T>(cams, C, obs, N, nanmask, zeromask);
+        const int V = __popc(nanmask | zeromask);
+        const int Lmax = active ? C - a.min_cams - V : -1;
+
+        double err_min = kInf;
+        double Qb[3] = {d_nan(), d_nan(), d_nan()};
+        int n_excl = C;
+        uint32_t mask = allmask;
 
         // ---- subset search, levels in lock step across the wave -----------------------------
-        unsigned long long pend_level = __ballot(need);
+        unsigned long long pend_level = __ballot(Lmax >= 1);
         for (int level = 1; pend_level != 0ull; ++level) {
             unsigned long long pending = pend_level;
             bool cont = false;                                      // owner lanes: continue to level+1
@@ -431,22 +546,20 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
                 const unsigned long long before = pending;
                 for (int i = 0; i < groups && pending; ++i) pending &= pending - 1;
                 const unsigned long long batch = before & ~pending;   // owners served in this pass
-                const int owner = nth_set_bit(batch, grp);            // unit this group works on (lane id) or -1
+                const int owner = nth_set_bit(batch, grp);            // record this group works on (lane id) or -1
 
                 // gather the owner's state
                 const int src = owner < 0 ? lane : owner;
                 const uint32_t o_nan = __shfl(nanmask, src, 64), o_zero = __shfl(zeromask, src, 64);
-                const int o_unit_raw = __shfl(u, src, 64);
-                const int o_unit = owner < 0 ? 0 : o_unit_raw;
                 double No[10];
 #pragma unroll
                 for (int i = 0; i < 10; ++i) No[i] = shfl_d(N[i], src);
                 const uint32_t o_d = o_nan | o_zero, o_valid = allmask & ~o_d;
                 const int oV = __popc(o_d);
-                const int ob = o_unit / K, ok = o_unit - ob * K;
-                UnitObs<T> oobs{tile + (size_t)ob * blk_elems + ok * 3, strideC, a.lik_thr};
+                const unsigned char *orec = recs + (size_t)src * a.rec_bytes;
+                UnitObs<T> oobs{reinterpret_cast<const T *>(orec + 8), 3, a.lik_thr};
                 UnitObs<T> oobs_sw = oobs;
-                if (LRSWAP) oobs_sw.p = tile + (size_t)ob * blk_elems + a.swap_idx[ok] * 3;
+                if (LRSWAP) oobs_sw.p = oobs.p + C * 3;
                 const int M = C - oV - level;                       // cameras left when `level` valid ones go (:437, 513)
 
                 // best candidates seen by this lane (plain / swap), lowest rank first
@@ -538,7 +651,7 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
 
         // ---- finalise (triangulation.py:588-604) ------------------------------------------
         if (active) {
-            const int64_t gu = tile0 * K + u;
+            const int64_t gu = a.block0 * a.K + u;
             const bool fail = !(err_min <= thr);
             double *Qo = a.Q + gu * 3;
             Qo[0] = fail ? d_nan() : Qb[0];
@@ -548,31 +661,34 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_kernel(const P2sTriArgs a) {
             a.n_excl[gu] = (uint8_t)n_excl;
             a.mask[gu] = mask;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next records overwrite this wave's LDS region
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-static hipError_t launch_t(const P2sTriArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-#define P2S_LAUNCH(U, L)                                                                                     \
-    do {                                                                                                     \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_kernel<T, U, L>),          \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
-        if (e != hipSuccess) return e;                                                                       \
-        hipLaunchKernelGGL((p2s_tri_kernel<T, U, L>), grid, block, lds, s, a);                                \
-        return hipGetLastError();                                                                            \
-    } while (0)
-    if (a.undistort) {
-        if (a.lr_swap) P2S_LAUNCH(true, true);
-        else P2S_LAUNCH(true, false);
-    } else {
-        if (a.lr_swap) P2S_LAUNCH(false, true);
-        else P2S_LAUNCH(false, false);
-    }
-#undef P2S_LAUNCH
+template <typename T, bool U, bool L>
+static hipError_t launch_both(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_level0_kernel<T, U, L>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, g.lds0);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_search_kernel<T, U, L>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, g.lds1);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((p2s_tri_level0_kernel<T, U, L>), dim3(g.grid0), dim3(g.threads0), g.lds0, s, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.debug_mode == 1) return hipSuccess;
+    hipLaunchKernelGGL((p2s_tri_search_kernel<T, U, L>), dim3(g.grid1), dim3(g.threads1), g.lds1, s, a);
+    return hipGetLastError();
 }
 
-hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, int grid, int threads, size_t lds, hipStream_t s) {
-    if (dtype == 0) return launch_t<float>(a, dim3(grid), dim3(threads), lds, s);
-    return launch_t<double>(a, dim3(grid), dim3(threads), lds, s);
+template <typename T>
+static hipError_t launch_t(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s) {
+    if (a.undistort) return a.lr_swap ? launch_both<T, true, true>(a, g, s) : launch_both<T, true, false>(a, g, s);
+    return a.lr_swap ? launch_both<T, false, true>(a, g, s) : launch_both<T, false, false>(a, g, s);
+}
+
+hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s) {
+    return dtype == 0 ? launch_t<float>(a, g, s) : launch_t<double>(a, g, s);
 }
