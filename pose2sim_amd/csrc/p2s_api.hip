@@ -297,8 +297,8 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     const int64_t shard_cap = (tiles_per_chunk + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * (int64_t)g.FB * n_kpts;
     const size_t list_bytes = (size_t)P2S_WL_SHARDS * shard_cap * rec_bytes;
     if ((rc = ctx->wl_rec.ensure(2 * list_bytes)) != P2S_OK) return rc;
-    if ((rc = ctx->wl_count.ensure((size_t)n_chunks * P2S_WL_SHARDS * sizeof(uint32_t))) != P2S_OK) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->wl_count.p, 0, (size_t)n_chunks * P2S_WL_SHARDS * sizeof(uint32_t), ctx->stream));
+    if ((rc = ctx->wl_count.ensure((size_t)n_chunks * 2 * P2S_WL_SHARDS * sizeof(uint32_t))) != P2S_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->wl_count.p, 0, (size_t)n_chunks * 2 * P2S_WL_SHARDS * sizeof(uint32_t), ctx->stream));
 
     // search kernel geometry: LDS = [P][binom][waves x 64 records]
     const int lds_binom_off = (C * 12 * 8 + 15) / 16 * 16;
@@ -328,18 +328,17 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     for (int64_t ch = 0; ch < n_chunks; ++ch) {
         a.block0 = ch * chunk_blocks;
         a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - a.block0);
-        a.wl_count = (uint32_t *)ctx->wl_count.p + ch * P2S_WL_SHARDS;
+        a.wl_count = (uint32_t *)ctx->wl_count.p + ch * 2 * P2S_WL_SHARDS;
         a.wl_rec = (unsigned char *)ctx->wl_rec.p + (size_t)(ch & 1) * list_bytes;
         P2sTriLaunch L{};
         L.grid0 = (int)((a.n_blocks + g.FB - 1) / g.FB);
         L.threads0 = g.threads;
         L.lds0 = g.lds_bytes;
-        // persistent search grid: a multiple of P2S_WL_SHARDS waves, at most 4096, no more than the
-        // chunk could ever need
-        const int64_t need_waves = (a.n_blocks * n_kpts + 63) / 64 + P2S_WL_SHARDS;
-        int64_t waves = std::min<int64_t>(4096, (need_waves + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * P2S_WL_SHARDS);
-        while (waves % wpb) waves += P2S_WL_SHARDS;
-        L.grid1 = (int)(waves / wpb);
+        // persistent search grid: what stays resident at 3 waves per SIMD (256 CUs x 12 waves), no
+        // more than the chunk could ever need
+        const int64_t need_waves = (a.n_blocks * n_kpts + 31) / 32;
+        const int64_t waves = std::max<int64_t>(wpb, std::min<int64_t>(3072, need_waves));
+        L.grid1 = (int)((waves + wpb - 1) / wpb);
         L.threads1 = 64 * wpb;
         L.lds1 = lds1;
         HIP_TRY(p2s_launch_tri(a, dtype, L, ctx->stream));

@@ -31,7 +31,7 @@ struct P2sTriArgs {
     uint32_t *mask;
     const P2sCam *cams;
     const uint32_t *binom;       // [33][33] binomial coefficients
-    uint32_t *wl_count;          // work list of this chunk: P2S_WL_SHARDS record counts (zeroed before kernel 1)
+    uint32_t *wl_count;          // work list of this chunk: P2S_WL_SHARDS record counts, then P2S_WL_SHARDS job tickets (zeroed before kernel 1)
     unsigned char *wl_rec;       // records: {u32 unit id in chunk, u32 pad, T obs[C][3] (, T obs_swapped[C][3])}
     int64_t block0;              // first (frame, person) block of this chunk
     int64_t n_blocks;            // blocks in this chunk

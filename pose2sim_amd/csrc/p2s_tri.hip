@@ -34,6 +34,8 @@ constexpr double kInf = __builtin_huge_val();
 // every uniform-index access become a scalar (SMEM) load and the value an SGPR operand.
 typedef const __attribute__((address_space(4))) P2sCam *cam_cptr;
 
+constexpr int P2S_JOB = 32;   // work-list records a search wave takes at a time (<= 64)
+
 __device__ __forceinline__ double d_nan() { return __builtin_nan(""); }
 
 // 1/d to ~1 ulp: v_rcp_f64 seed + two Newton steps (the IEEE division sequence costs about
@@ -85,21 +87,26 @@ __device__ __forceinline__ void accum_camera(double N[10], PT P, double x, doubl
     N[9] = fma(s3, a3, fma(t3, b3, N[9]));
 }
 
-// Smallest eigenvector of the 4x4 SPD matrix N, dehomogenised: v = (q, 1), N v = lambda v.
-// With N = [[M, b], [b^T, c]]: (M - lambda I) q = -b and lambda = c + b.q.  Newton on that secular
-// equation (== Rayleigh-quotient update) from lambda = 0, i.e. from the inhomogeneous least-squares
-// point; monotone and quadratically convergent below the smallest eigenvalue of M.  The 3x3
-// systems are solved through the adjugate (one reciprocal).  Returns q = V[0:3,3]/V[3,3] of the
-// reference's SVD (common.py:348-350) to ~1e-12 relative.
+// Smallest eigenvector of the 4x4 SPD matrix N, dehomogenised: v = (q, 1), N v = lambda v, i.e.
+// q = V[0:3,3]/V[3,3] of the reference's SVD of A (common.py:348-350), N = A^T A.
+//
+// With N = [[M, b], [b^T, c]]: (M - lambda I) q = -b and f(lambda) = c - lambda + b.q(lambda) = 0.
+// On (-inf, mu_1) (mu_1 = smallest eigenvalue of M) f is decreasing and concave and its only root
+// there is the smallest eigenvalue of N (interlacing).  Halley's iteration from lambda = 0 -- the
+// inhomogeneous least-squares point -- converges cubically; an iterate that jumps over the pole
+// mu_1 (M - lambda I no longer positive definite) is pulled back by bisection, so the SMALLEST
+// root is the one found.  The 3x3 systems go through the adjugate (one reciprocal).  The loop
+// stops on a first-order bound of the error of q and returns q + dlambda * dq/dlambda; agreement
+// with the SVD is ~1e-10 relative (tests/test_tri_gpu.py).
 __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3]) {
     const double b0 = N[3], b1 = N[6], b2 = N[8], c = N[9];
     const double m01 = N[1], m02 = N[2], m12 = N[5];
     const double tol_abs = 2e-15 * fabs(c);
-    double lam = 0.0;
-    double q0 = 0, q1 = 0, q2 = 0;
+    double lam = 0.0, lo = 0.0, hi = kInf;
+    double q0 = d_nan(), q1 = d_nan(), q2 = d_nan();
     bool done = false;
 #pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 10; ++it) {
         const double m00 = N[0] - lam, m11 = N[4] - lam, m22 = N[7] - lam;
         const double c00 = fma(m11, m22, -m12 * m12);
         const double c01 = fma(m02, m12, -m01 * m22);
@@ -108,18 +115,35 @@ __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3])
         const double c12 = fma(m01, m02, -m00 * m12);
         const double c22 = fma(m00, m11, -m01 * m01);
         const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
+        const bool pd = (m00 > 0.0) && (c22 > 0.0) && (det > 0.0);
         const double nid = -fast_rcp(det);
-        const double y0 = (c00 * b0 + c01 * b1 + c02 * b2) * nid;
+        const double y0 = (c00 * b0 + c01 * b1 + c02 * b2) * nid;      // q(lambda)
         const double y1 = (c01 * b0 + c11 * b1 + c12 * b2) * nid;
         const double y2 = (c02 * b0 + c12 * b1 + c22 * b2) * nid;
-        if (!done) { q0 = y0; q1 = y1; q2 = y2; }
-        const double g = c + (b0 * y0 + b1 * y1 + b2 * y2) - lam;
-        const double qq = 1.0 + (y0 * y0 + y1 * y1 + y2 * y2);
-        const double lam_new = fma(g, fast_rcp(qq), lam);
-        const bool conv = fabs(lam_new - lam) <= 1e-9 * fabs(lam_new) + tol_abs;
+        const double p0 = -(c00 * y0 + c01 * y1 + c02 * y2) * nid;     // dq/dlambda = (M - lambda)^-1 q
+        const double p1 = -(c01 * y0 + c11 * y1 + c12 * y2) * nid;
+        const double p2 = -(c02 * y0 + c12 * y1 + c22 * y2) * nid;
+        const double f = c + (b0 * y0 + b1 * y1 + b2 * y2) - lam;
+        const double qq = 1.0 + (y0 * y0 + y1 * y1 + y2 * y2);          // -f'
+        const double qp = y0 * p0 + y1 * p1 + y2 * p2;                  // -f''/2
+        const double pp = p0 * p0 + p1 * p1 + p2 * p2;
+        const double den = fma(qq, qq, f * qp);
+        const double rq = fast_rcp(qq);
+        const double step = (den > 0.0) ? f * qq * fast_rcp(den) : f * rq;   // Halley, else Newton
+        // |error of lambda + step| <~ |f''/(2f')| step^2 (Newton's bound; Halley's is smaller),
+        // times |dq/dlambda| gives the error of the corrected q
+        const double t = qp * step * step * rq;
+        const bool conv = pd && ((t * t * pp <= 1e-21 * qq) || (fabs(step) <= tol_abs));
+        if (!done && pd) { q0 = fma(step, p0, y0); q1 = fma(step, p1, y1); q2 = fma(step, p2, y2); }
+        double lam_new = lam + step;
+        lo = (pd && f >= 0.0) ? lam : lo;
+        hi = pd ? hi : fmin(hi, lam);
+        lam_new = pd ? lam_new : 0.5 * (lo + hi);
+        lam_new = (lam_new >= hi) ? 0.5 * (lam + hi) : lam_new;
+        // NaN system, or no positive-definite point at all (rank-deficient N): give up at once
+        const bool bad = !(lam_new == lam_new) || (!pd && !(hi > lo));
         if (!done) lam = lam_new;
-        // a NaN system never converges; give up on it at once
-        done = done || conv || !(lam_new == lam_new);
+        done = done || conv || bad;
         if (__all(done)) break;
     }
     q[0] = q0; q[1] = q1; q[2] = q2;
@@ -132,16 +156,6 @@ __device__ __forceinline__ double pair_distance(double dx, double dy) {
     const double sx = nx ? 0.0 : dx * dx;
     const double sy = ny ? 0.0 : dy * dy;
     return (nx && ny) ? kInf : fast_sqrt(sx + sy);
-}
-
-// reprojection (common.py:357-375); P through the scalar cache
-__device__ __forceinline__ void project_pinhole(cam_cptr cam, const double q[3], double &u, double &v) {
-    const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
-    const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], fma(cam->P[6], q[2], cam->P[7])));
-    const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], fma(cam->P[10], q[2], cam->P[11])));
-    const double rz = fast_rcp(z);
-    u = a * rz;
-    v = b * rz;
 }
 
 // cv2.projectPoints with the ORIGINAL intrinsics and distortion (triangulation.py:473, quirk Q4).
@@ -225,6 +239,10 @@ struct UnitObs {
         const T *q = p + c * stride;
         x = (double)q[0]; y = (double)q[1]; w = (double)q[2];
     }
+    __device__ __forceinline__ void rawT(int c, T &x, T &y, T &w) const {
+        const T *q = p + c * stride;
+        x = q[0]; y = q[1]; w = q[2];
+    }
     __device__ __forceinline__ void masked_xy(int c, double &x, double &y) const {
         double w;
         raw(c, x, y, w);
@@ -241,15 +259,53 @@ __device__ __forceinline__ void classify_and_accumulate(cam_cptr cams, int C, co
                                                          uint32_t &nanmask, uint32_t &zeromask) {
 #pragma unroll 2
     for (int c = 0; c < C; ++c) {
-        double x, y, w;
-        o.raw(c, x, y, w);
-        const bool isn = !(w == w) || (w < o.lik_thr);
-        const bool isz = (w == 0.0) && !isn;
+        T x, y, w;
+        o.rawT(c, x, y, w);
+        const bool isn = !(w == w) || ((double)w < o.lik_thr);
+        const bool isz = (w == (T)0) && !isn;
         nanmask |= isn ? (1u << c) : 0u;
         zeromask |= isz ? (1u << c) : 0u;
         const bool ok = !(isn || isz);
-        accum_camera<1>(N, cams[c].P, ok ? x : 0.0, ok ? y : 0.0, ok ? w : 0.0);
+        accum_camera<1>(N, cams[c].P, (double)(ok ? x : (T)0), (double)(ok ? y : (T)0), (double)(ok ? w : (T)0));
     }
+}
+
+// 1/sqrt(t) for 0 < t < inf to ~1 ulp: v_rsq_f64 seed + two Newton steps.
+__device__ __forceinline__ double fast_rsqrt(double t) {
+    double r = __builtin_amdgcn_rsq(t);
+    double e = fma(-t * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    e = fma(-t * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    return r;
+}
+
+// Reprojection distance of one camera (common.py:357-403).  With a = P0.Q, b = P1.Q, z = P2.Q:
+// |(a/z - x, b/z - y)| = s / sqrt(s z^2), s = (a - x z)^2 + (b - y z)^2: one reciprocal square
+// root instead of a division and a square root.  Degenerate or NaN operands (s z^2 not in (0, inf))
+// take the literal formula with the reference's NaN rules; `wanted` keeps cameras whose distance is
+// not used from dragging the wave onto that path.
+template <bool UNDISTORT>
+__device__ __forceinline__ double camera_distance(cam_cptr cam, const double q[3], double x, double y, bool wanted) {
+    if (UNDISTORT) {
+        double u, v;
+        project_distorted(cam, q, u, v);
+        return pair_distance(u - x, v - y);
+    }
+    const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
+    const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], fma(cam->P[6], q[2], cam->P[7])));
+    const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], fma(cam->P[10], q[2], cam->P[11])));
+    const double dxz = fma(-x, z, a), dyz = fma(-y, z, b);
+    const double s = fma(dxz, dxz, dyz * dyz);
+    const double t = s * z * z;
+    double d = s * fast_rsqrt(t);
+    const bool regular = (t > 0.0) && (t < kInf);
+    if (__any(wanted && !regular)) {
+        const double rz = fast_rcp(z);
+        const double slow = pair_distance(a * rz - x, b * rz - y);
+        d = regular ? d : slow;
+    }
+    return d;
 }
 
 // Mean reprojection error over the cameras of `kept` (triangulation.py:472-489).
@@ -259,12 +315,11 @@ __device__ __forceinline__ double mean_error(cam_cptr cams, int C, const UnitObs
     double sum = 0.0;
 #pragma unroll 2
     for (int c = 0; c < C; ++c) {
-        double x, y, w, u, v;
+        double x, y, w;
         o.raw(c, x, y, w);
-        if (UNDISTORT) project_distorted(cams + c, q, u, v);
-        else project_pinhole(cams + c, q, u, v);
-        const double d = pair_distance(u - x, v - y);
-        sum += ((kept >> c) & 1u) ? d : 0.0;
+        const bool k = (kept >> c) & 1u;
+        const double d = camera_distance<UNDISTORT>(cams + c, q, x, y, k);
+        sum += k ? d : 0.0;
     }
     return sum * fast_rcp((double)__popc(kept));   // no camera kept -> NaN, as np.mean([])
 }
@@ -292,12 +347,10 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const Uni
     double sum = 0.0;
     taken = 0;
     for (int c = 0; c < C; ++c) {
-        double xs, ys, u, v;
+        double xs, ys;
         osw.masked_xy(c, xs, ys);
-        if (UNDISTORT) project_distorted(cams + c, qs, u, v);
-        else project_pinhole(cams + c, qs, u, v);
-        const double d = pair_distance(u - xs, v - ys);
         const bool k = ((kept >> c) & 1u) && taken < M;
+        const double d = camera_distance<UNDISTORT>(cams + c, qs, xs, ys, k);
         sum += k ? d : 0.0;
         taken += ((kept >> c) & 1u) ? 1 : 0;
     }
@@ -461,7 +514,7 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
 // ---------------------------------------------------------------------------------------------
 // Kernel 2 -- camera-subset search over the work list.  One wave owns 64 records at a time
 // (lane i = record i); LDS: [P: C*12 doubles][binom: 33*33 u32][per wave: 64 records].
-// Persistent grid: waves stride over the list whose length kernel 1 left in *wl_count.
+// Persistent grid: waves pull jobs from the sharded list whose lengths kernel 1 left in wl_count.
 template <typename T, bool UNDISTORT, bool LRSWAP>
 __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -479,17 +532,22 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
     for (int i = tid; i < 33 * 33; i += blockDim.x) sBinom[i] = a.binom[i];
     __syncthreads();
 
-    // wave w works on shard w % SHARDS, taking every (waves / SHARDS)-th group of 64 records
+    // Wave w serves shard w % SHARDS (shards fill evenly: every SHARDS-th tile); the waves of a shard
+    // pull jobs of P2S_JOB records through the shard's atomic ticket until it is drained.
     const uint32_t gwave = blockIdx.x * waves_per_block + wave;
-    const uint32_t n_waves = gridDim.x * waves_per_block;          // a multiple of P2S_WL_SHARDS (host)
-    const uint32_t shard = gwave % P2S_WL_SHARDS;
-    const uint32_t count = min(a.wl_count[shard], a.wl_capacity);
     const double thr = a.thr;
     const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
-    const uint32_t wave_stride = (n_waves / P2S_WL_SHARDS) * 64u;
+    const uint32_t shard = gwave % P2S_WL_SHARDS;
+    uint32_t *ticket = a.wl_count + P2S_WL_SHARDS + shard;
+    const uint32_t count = min(a.wl_count[shard], a.wl_capacity);
 
-    for (uint32_t rec0 = (gwave / P2S_WL_SHARDS) * 64u; rec0 < count; rec0 += wave_stride) {
-        const int n = (int)min(64u, count - rec0);
+    for (;;) {
+        uint32_t job = 0;
+        if (lane == 0) job = atomicAdd(ticket, 1u);
+        job = __shfl(job, 0, 64);
+        const uint32_t rec0 = job * P2S_JOB;
+        if (rec0 >= count) break;                                  // shard drained
+        const int n = (int)min((uint32_t)P2S_JOB, count - rec0);
         // ---- this wave's records: contiguous copy into its LDS region ----------------------
         {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(a.wl_rec + ((size_t)shard * a.wl_capacity + rec0) * a.rec_bytes);
