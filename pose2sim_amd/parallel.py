@@ -1,0 +1,97 @@
+"""Frame sharding across the GPUs of one node.
+
+Every (frame, person, keypoint) unit is independent, so rank r of G takes the contiguous frame
+block [r*F/G, (r+1)*F/G); the only exchange step is ONE all-gather of the packed per-unit results
+(32 + 1 bytes per unit) -- RCCL over xGMI when the process group is 'nccl', gloo on CPU in tests.
+The sequential post-processing (tracking, interpolation, .trc) then runs on every rank's copy and
+only rank 0 writes files.
+"""
+import numpy as np
+
+
+def dist_info():
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def shard_bounds(n_frames, rank, world):
+    """Contiguous frame block of `rank`: sizes differ by at most one, earlier ranks get the extra."""
+    base, extra = divmod(n_frames, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def pack_results(Q, err, nex, mask):
+    """[n][K] results -> one contiguous uint8 buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8]."""
+    parts = [np.ascontiguousarray(Q, dtype=np.float64).view(np.uint8).ravel(),
+             np.ascontiguousarray(err, dtype=np.float32).view(np.uint8).ravel(),
+             np.ascontiguousarray(mask, dtype=np.uint32).view(np.uint8).ravel(),
+             np.ascontiguousarray(nex, dtype=np.uint8).ravel()]
+    return np.concatenate(parts)
+
+
+def unpack_results(buf, n_blocks, K):
+    n = n_blocks * K
+    o = 0
+    Q = buf[o:o + n * 24].view(np.float64).reshape(n_blocks, K, 3); o += n * 24
+    err = buf[o:o + n * 4].view(np.float32).reshape(n_blocks, K); o += n * 4
+    mask = buf[o:o + n * 4].view(np.uint32).reshape(n_blocks, K); o += n * 4
+    nex = buf[o:o + n].reshape(n_blocks, K)
+    return Q, err, nex, mask
+
+
+def sharded_triangulate(compute, xyl):
+    """Run ``compute(xyl_shard) -> (Q, err, n_excl, mask)`` on this rank's frames and all-gather.
+
+    xyl: [F][Pn][C][K][3] (every rank holds, or can load, the same tensor; only its shard is read).
+    Returns the full-size (Q [F][Pn][K][3], err, n_excl, mask) on every rank.
+    """
+    rank, world = dist_info()
+    F, Pn, K = xyl.shape[0], xyl.shape[1], xyl.shape[3]
+    if world == 1:
+        return compute(xyl)
+    import torch
+    import torch.distributed as dist
+    lo, hi = shard_bounds(F, rank, world)
+    Q, err, nex, mask = compute(xyl[lo:hi])
+    nb_max = (shard_bounds(F, 0, world)[1] - shard_bounds(F, 0, world)[0]) * Pn
+    per_unit = 24 + 4 + 4 + 1
+    local = np.zeros(nb_max * K * per_unit, dtype=np.uint8)
+    packed = pack_results(Q, err, nex, mask)
+    # sections are sized for the local block count: repack into the padded layout
+    nb = (hi - lo) * Pn
+    padded = pack_results(_pad(Q.reshape(nb, K, 3), nb_max), _pad(err.reshape(nb, K), nb_max),
+                          _pad(nex.reshape(nb, K), nb_max), _pad(mask.reshape(nb, K), nb_max)) if nb != nb_max else packed
+    local[:] = padded
+    backend = dist.get_backend()
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    t_local = torch.from_numpy(local).to(dev)
+    t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(t_all, t_local)          # the single collective of the path
+    allbuf = t_all.cpu().numpy().reshape(world, -1)
+    outs = []
+    for r in range(world):
+        rlo, rhi = shard_bounds(F, r, world)
+        q, e, n, m = unpack_results(allbuf[r], nb_max, K)
+        k = (rhi - rlo) * Pn
+        outs.append((q[:k], e[:k], n[:k], m[:k]))
+    Qf = np.concatenate([o[0] for o in outs]).reshape(F, Pn, K, 3)
+    ef = np.concatenate([o[1] for o in outs]).reshape(F, Pn, K)
+    nf = np.concatenate([o[2] for o in outs]).reshape(F, Pn, K)
+    mf = np.concatenate([o[3] for o in outs]).reshape(F, Pn, K)
+    return Qf, ef, nf, mf
+
+
+def _pad(a, n):
+    if a.shape[0] == n:
+        return a
+    out = np.zeros((n,) + a.shape[1:], dtype=a.dtype)
+    out[:a.shape[0]] = a
+    return out

@@ -1,0 +1,315 @@
+"""Robust triangulation stage: drop-in for the reference's ``triangulate_all(config_dict)``
+(triangulation.py:656-959), with the per-(frame x person x keypoint) work on the MI355X.
+
+The frame / person / keypoint loops (triangulation.py:796-845) become ONE call into the HIP
+engine over the packed tensor of every frame; what stays on the host is what carries state
+from frame to frame: person tracking (:847-865), interpolation (:889-894), valid-section
+trimming (:897-919), gap filling (:922-926), the .trc writer (:929) and the recap log (:959).
+There is no CPU fallback for the kernel work.
+"""
+import logging
+import os
+
+import numpy as np
+import pandas as pd
+
+from . import calib as calib_mod
+from . import poseio, postproc, skeletons, trc
+from . import parallel
+
+
+def _make_engine():
+    """The compute backend: one HIP engine on this rank's GPU (LOCAL_RANK, default 0)."""
+    from .engine import Engine
+    return Engine(int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def _session_dir(project_dir):
+    """triangulation.py:680-682."""
+    session_dir = os.path.realpath(os.path.join(project_dir, '..'))
+    return session_dir if 'Config.toml' in os.listdir(session_dir) else os.getcwd()
+
+
+def select_pose_inputs(project_dir):
+    """triangulation.py:751-772: camera folders come from <project>/pose, the files from
+    pose-associated, else pose-sync, else pose.  Returns (pose_dir_used, json_dirs, json_files)."""
+    pose_dir = os.path.join(project_dir, 'pose')
+    poseSync_dir = os.path.join(project_dir, 'pose-sync')
+    poseTracked_dir = os.path.join(project_dir, 'pose-associated')
+    try:
+        pose_listdirs_names = next(os.walk(pose_dir))[1]
+        os.listdir(os.path.join(pose_dir, pose_listdirs_names[0]))[0]
+    except Exception:
+        raise ValueError(f'No json files found in {pose_dir} subdirectories. Make sure you run Pose2Sim.poseEstimation() first.')
+    pose_listdirs_names = poseio.sort_stringlist_by_last_number(pose_listdirs_names)
+    json_dirs_names = [k for k in pose_listdirs_names if 'json' in k]
+    try:
+        json_files_names = poseio.list_json_files(poseTracked_dir, json_dirs_names)
+        used = poseTracked_dir
+    except Exception:
+        try:
+            json_files_names = poseio.list_json_files(poseSync_dir, json_dirs_names)
+            used = poseSync_dir
+        except Exception:
+            try:
+                json_files_names = poseio.list_json_files(pose_dir, json_dirs_names)
+                used = pose_dir
+            except Exception:
+                raise Exception(f'No json files found in {pose_dir}, {poseSync_dir}, nor {poseTracked_dir} subdirectories. Make sure you run Pose2Sim.poseEstimation() first.')
+    return used, json_dirs_names, json_files_names
+
+
+def track_persons(Q, err, nex, ids_mask, f_range, multi_person, max_distance_m, n_cams):
+    """triangulation.py:823-874 on the kernel's outputs, frame by frame.
+
+    Q [F][P][K][3], err [F][P][K], nex [F][P][K], ids_mask [F][P][K] (bit c = camera c excluded).
+    Returns the per-frame, per-person rows the reference appends to Q_tot / error_tot /
+    nb_cams_excluded_tot / id_excluded_cams_tot (persons 0..P-1 only, :870-874).
+    """
+    F, P, K, _ = Q.shape
+    if not multi_person:
+        return Q, err.astype(np.float64), nex.astype(np.float64), ids_mask
+    allmask = np.uint32((1 << n_cams) - 1) if n_cams < 32 else np.uint32(0xFFFFFFFF)
+    Q_out = np.empty((F, P, K, 3))
+    e_out = np.empty((F, P, K))
+    n_out = np.empty((F, P, K))
+    m_out = np.empty((F, P, K), dtype=np.uint32)
+    Q_cur = np.full((P, K, 3), np.nan)
+    Q_old = np.full((P, K, 3), np.nan)
+    for fi, f in enumerate(range(*f_range)):
+        nan_mask = np.isnan(Q_cur)
+        Q_old = np.where(nan_mask, Q_old, Q_cur)                      # :824-825
+        Q_cur = Q[fi]
+        e_f, n_f, m_f = err[fi].astype(np.float64), nex[fi].astype(np.float64), ids_mask[fi]
+        if f != 0:                                                    # :850 absolute frame number (quirk Q7)
+            Q_old, Q_cur, sorted_ids = postproc.sort_people_sports2d(Q_old, np.array(Q_cur), max_dist=max_distance_m)
+            e_s = np.full((P, K), np.nan)
+            n_s = np.full((P, K), float(n_cams))
+            m_s = np.full((P, K), allmask, dtype=np.uint32)
+            for n in range(P):                                        # :855-864
+                d = int(sorted_ids[n])
+                if d >= 0:
+                    e_s[n], n_s[n], m_s[n] = e_f[d], n_f[d], m_f[d]
+            e_f, n_f, m_f = e_s, n_s, m_s
+        Q_out[fi] = Q_cur[:P]
+        e_out[fi], n_out[fi], m_out[fi] = e_f, n_f, m_f
+    return Q_out, e_out, n_out, m_out
+
+
+def _cam_exclusion_fractions(mask_rows, n_cams, K):
+    """triangulation.py:933-943 from the excluded-camera bit masks of the kept frames."""
+    frame_count = mask_rows.shape[0]
+    total = frame_count * K
+    counts = {}
+    flat = mask_rows.reshape(-1).astype(np.uint64)
+    for c in range(n_cams):
+        counts[c] = int(np.count_nonzero((flat >> np.uint64(c)) & np.uint64(1))) / total
+    return counts
+
+
+def triangulate_all(config_dict):
+    """Same contract as the reference: reads <session>/calib*/*.toml and the pose JSON folders of
+    config_dict['project']['project_dir'], writes <project>/pose-3d/<name>[_P<n>]_<f0>-<f1>.trc."""
+    project_dir = config_dict.get('project').get('project_dir')
+    session_dir = _session_dir(project_dir)
+    multi_person = config_dict.get('project').get('multi_person')
+    pose_model = config_dict.get('pose').get('pose_model')
+    frame_range = config_dict.get('project').get('frame_range')
+    tcfg = config_dict.get('triangulation')
+    likelihood_threshold = tcfg.get('likelihood_threshold_triangulation')
+    error_threshold = tcfg.get('reproj_error_threshold_triangulation')
+    min_cameras = tcfg.get('min_cameras_for_triangulation')
+    interpolation_kind = tcfg.get('interpolation')
+    interp_gap_smaller_than = tcfg.get('interp_if_gap_smaller_than')
+    max_distance_m = tcfg.get('max_distance_m', None)
+    remove_incomplete_frames = tcfg.get('remove_incomplete_frames', False)
+    sections_to_keep = tcfg.get('sections_to_keep')
+    min_chunk_size = tcfg.get('min_chunk_size', 10)
+    fill_large_gaps_with = tcfg.get('fill_large_gaps_with')
+    show_interp_indices = tcfg.get('show_interp_indices')
+    undistort_points = tcfg.get('undistort_points')
+    handle_LR_swap = tcfg.get('handle_LR_swap')
+    make_c3d = tcfg.get('make_c3d')
+
+    calib_file = calib_mod.find_calibration_file(session_dir)
+    P = calib_mod.computeP(calib_file, undistort=undistort_points)
+    calib_params = calib_mod.retrieve_calib_params(calib_file)
+
+    keypoints_ids, keypoints_names, keypoints_idx_swapped = skeletons.keypoints(pose_model, config_dict)
+    keypoints_nb = len(keypoints_ids)
+    if keypoints_idx_swapped == list(range(keypoints_nb)) and not skeletons.swap_indices(keypoints_names)[1]:
+        logging.warning('No left/right swap was performed.')
+
+    pose_dir, json_dirs_names, json_files_names = select_pose_inputs(project_dir)
+    n_cams = len(json_dirs_names)
+
+    f_range = [[0, min([len(j) for j in json_files_names])] if frame_range in ('all', 'auto', []) else frame_range][0]
+    if n_cams != len(P):
+        raise Exception(f'Error: The number of cameras is not consistent: Found {len(P)} cameras in the calibration file, and {n_cams} cameras based on the number of pose folders.')
+
+    if multi_person:
+        nb_persons = max(max(poseio.count_persons(os.path.join(pose_dir, json_dirs_names[c], name))
+                             for name in json_files_names[c]) for c in range(n_cams))
+    else:
+        nb_persons = 1
+
+    # ---- every frame at once: JSON -> packed tensor -> HIP engine ----------------------------
+    maps = poseio.frame_file_map(json_files_names)
+    xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, f_range, keypoints_ids, nb_persons)
+    engine = _make_engine()
+    engine.set_calibration(P, calib_params if undistort_points else None)
+    prm = engine.tri_params(error_threshold, likelihood_threshold, min_cameras, undistort_points, handle_LR_swap)
+
+    def compute(x):
+        return engine.triangulate(x, prm, keypoints_idx_swapped if handle_LR_swap else None)
+    Qk, ek, nk, mk = parallel.sharded_triangulate(compute, xyl)
+    rank, _ = parallel.dist_info()
+
+    Q_rows, e_rows, n_rows, m_rows = track_persons(Qk, ek, nk, mk, f_range, multi_person, max_distance_m, n_cams)
+    index = range(*f_range)
+    Q_tot = [pd.DataFrame(Q_rows[:, n].reshape(len(index), keypoints_nb * 3), index=index) for n in range(nb_persons)]
+    error_tot = [pd.DataFrame(e_rows[:, n].astype(np.float64), index=index) for n in range(nb_persons)]
+    nb_cams_excluded_tot = [pd.DataFrame(n_rows[:, n].astype(np.float64), index=index) for n in range(nb_persons)]
+
+    cam_excluded_count, interp_frames, non_interp_frames, f_range_trimmed, trc_paths = [], [], [], [], []
+    for n in range(nb_persons):
+        if interpolation_kind != 'none':                                      # :889-894
+            try:
+                Q_tot[n] = Q_tot[n].apply(postproc.interpolate_zeros_nans, axis=0, args=[interp_gap_smaller_than, interpolation_kind])
+            except Exception:
+                logging.warning(f'Interpolation was not possible for person {n}. This means that not enough points are available, which is often due to a bad calibration.')
+
+        error_tot[n]['mean'] = error_tot[n].mean(axis=1, skipna=not remove_incomplete_frames)   # :897
+        nb_cams_excluded_tot[n]['mean'] = nb_cams_excluded_tot[n].mean(axis=1)
+        start, end = postproc.indices_of_first_last_non_nan_chunks(error_tot[n]['mean'], min_chunk_size=min_chunk_size,
+                                                                   chunk_choice_method=sections_to_keep)
+        f_range_trimmed.append([start, end])
+
+        if end - start <= min_chunk_size:                                     # :903-910
+            nb_cams_excluded_tot[n] = pd.DataFrame(columns=nb_cams_excluded_tot[n].columns)
+            cam_excluded_count.append({})
+            interp_frames.append([])
+            non_interp_frames.append([])
+            trc_paths.append('')
+            logging.info(f'\nPerson {n}: Less than {min_chunk_size} valid frames in a row. Deleting person.')
+            continue
+
+        Q_tot[n] = Q_tot[n].iloc[start:end]                                  # :913-916
+        error_tot[n] = error_tot[n].iloc[start:end]
+        nb_cams_excluded_tot[n] = nb_cams_excluded_tot[n].iloc[start:end]
+        masks_kept = m_rows[start:end, n]
+        zero_nan_frames = np.where(Q_tot[n].iloc[:, ::3].T.eq(0) | ~np.isfinite(Q_tot[n].iloc[:, ::3].T))
+        zero_nan_frames_per_kpt = [zero_nan_frames[1][np.where(zero_nan_frames[0] == k)[0]] for k in range(keypoints_nb)]
+        zero_nan_frames_per_kpt = [z[(start < z) & (end > z)] for z in zero_nan_frames_per_kpt]
+
+        if fill_large_gaps_with == 'last_value':                              # :922-926
+            Q_tot[n] = Q_tot[n].ffill(axis=0).bfill(axis=0)
+            Q_tot[n] = Q_tot[n].replace([np.nan, np.inf], 0)
+        elif fill_large_gaps_with == 'zeros':
+            Q_tot[n] = Q_tot[n].replace([np.nan, np.inf], 0)
+
+        if rank == 0:
+            trc_paths.append(trc.make_trc(config_dict, Q_tot[n], keypoints_names, id_person=n))   # :929
+            if make_c3d:
+                logging.warning('make_c3d: the c3d package is not available in this build; only the .trc file was written.')
+        else:
+            trc_paths.append('')
+
+        cam_excluded_count.append(_cam_exclusion_fractions(masks_kept, n_cams, keypoints_nb))   # :933-943
+
+        if show_interp_indices:                                               # :946-953
+            gaps = [np.where(np.diff(zero_nan_frames_per_kpt[k]) > 1)[0] + 1 for k in range(keypoints_nb)]
+            sequences = [np.split(zero_nan_frames_per_kpt[k], gaps[k]) for k in range(keypoints_nb)]
+            interp_frames.append([[f'{seq[0]}:{seq[-1]}' for seq in seq_kpt if len(seq) <= interp_gap_smaller_than and len(seq) > 0] for seq_kpt in sequences])
+            non_interp_frames.append([[f'{seq[0]}:{seq[-1]}' for seq in seq_kpt if len(seq) > interp_gap_smaller_than] for seq_kpt in sequences])
+        else:
+            interp_frames.append(None)
+            non_interp_frames.append([])
+
+    if np.all(np.diff(np.array(f_range_trimmed)) == 0):                       # :955-956
+        raise Exception('No persons have been triangulated. Please check your calibration and your synchronization, or the triangulation parameters in Config.toml.')
+
+    if rank == 0:
+        recap_triangulate(config_dict, error_tot, nb_cams_excluded_tot, keypoints_names, cam_excluded_count,
+                          interp_frames, non_interp_frames, f_range_trimmed, f_range, trc_paths, calib_file)
+    return trc_paths
+
+
+def recap_triangulate(config_dict, error, nb_cams_excluded, keypoints_names, cam_excluded_count, interp_frames,
+                      non_interp_frames, f_range_trimmed, f_range, trc_paths, calib_file):
+    """Log lines of triangulation.py:255-360."""
+    calib = calib_mod.load_toml(calib_file)
+    cal_keys = calib_mod.camera_keys(calib)
+    cam_names = np.array([calib[c].get('name') if calib[c].get('name') else c for c in cal_keys])
+    tcfg = config_dict.get('triangulation')
+    error_threshold_triangulation = tcfg.get('reproj_error_threshold_triangulation')
+    likelihood_threshold = tcfg.get('likelihood_threshold_triangulation')
+    min_chunk_size = tcfg.get('min_chunk_size', 10)
+    show_interp_indices = tcfg.get('show_interp_indices')
+    interpolation_kind = tcfg.get('interpolation')
+    interp_gap_smaller_than = tcfg.get('interp_if_gap_smaller_than')
+    fill_large_gaps_with = tcfg.get('fill_large_gaps_with')
+    make_c3d = tcfg.get('make_c3d')
+    handle_LR_swap = tcfg.get('handle_LR_swap')
+    undistort_points = tcfg.get('undistort_points')
+
+    calib_cam1 = calib[cal_keys[0]]
+    fm = calib_cam1['matrix'][0][0]
+    Dm = float(np.sqrt(np.sum(np.array(calib_cam1['translation'], dtype=np.float64) ** 2)))
+
+    logging.info('')
+    nb_persons = len(error)
+    for n in range(nb_persons):
+        first, last = f_range_trimmed[n]
+        if last - first <= min_chunk_size:
+            continue
+        if nb_persons > 1:
+            logging.info(f'\n\nPARTICIPANT {n}\n')
+        for idx, name in enumerate(keypoints_names):
+            mean_error_keypoint_px = np.around(error[n].iloc[:, idx].mean(), decimals=1)
+            mean_error_keypoint_m = np.around(mean_error_keypoint_px * Dm / fm, decimals=3)
+            mean_cam_excluded_keypoint = np.around(nb_cams_excluded[n].iloc[:, idx].mean(), decimals=2)
+            logging.info(f'Mean reprojection error for {name} is {mean_error_keypoint_px} px (~ {mean_error_keypoint_m} m), reached with {mean_cam_excluded_keypoint} excluded cameras. ')
+            if show_interp_indices:
+                if interpolation_kind != 'none':
+                    if len(list(interp_frames[n][idx])) == 0 and len(list(non_interp_frames[n][idx])) == 0:
+                        logging.info('  No frames needed to be interpolated.')
+                    if len(list(interp_frames[n][idx])) > 0:
+                        s = str(interp_frames[n][idx]).replace(':', ' to ').replace("'", '').replace(']', '').replace('[', '')
+                        logging.info(f'  Frames {s} were interpolated.')
+                    if len(list(non_interp_frames[n][idx])) > 0:
+                        s = str(non_interp_frames[n][idx]).replace(':', ' to ').replace("'", '').replace(']', '').replace('[', '')
+                        logging.info(f'  Frames {s} were not interpolated.')
+                else:
+                    logging.info("  No frames were interpolated because 'interpolation_kind' was set to none. ")
+
+        mean_error_px = np.around(error[n]['mean'].mean(), decimals=1)
+        mean_error_mm = np.around(mean_error_px * Dm / fm * 1000, decimals=1)
+        mean_cam_excluded = np.around(nb_cams_excluded[n]['mean'].mean(), decimals=2)
+        logging.info(f'\n--> Mean reprojection error for all points on frames {first} to {last} is {mean_error_px} px, which roughly corresponds to {mean_error_mm} mm. ')
+        logging.info(f'Cameras were excluded if likelihood was below {likelihood_threshold} and if the reprojection error was above {error_threshold_triangulation} px.')
+        if interpolation_kind != 'none':
+            filler = 'the last valid value' if fill_large_gaps_with == 'last_value' else 'zeros' if fill_large_gaps_with == 'zeros' else 'NaNs'
+            logging.info(f'Gaps were interpolated with {interpolation_kind} method if smaller than {interp_gap_smaller_than} frames. Larger gaps were filled with {filler}.')
+        logging.info(f'In average, {mean_cam_excluded} cameras had to be excluded to reach these thresholds.')
+        if len(range(first, last)) < len(range(*f_range)):
+            logging.warning(f'\nSome frames could not be correctly triangulated: trial trimmed between frames {f_range_trimmed[n]}.\n' +
+                            'You might need to tweak the triangulation parameters in Config.toml (for example, try increasing "reproj_error_threshold_triangulation").')
+        named = {cam_names[i]: v for i, v in cam_excluded_count[n].items()}
+        named = {k: v for k, v in sorted(named.items(), key=lambda item: item[1])[::-1]}
+        msg = ''
+        for i, (k, v) in enumerate(named.items()):
+            if i == 0:
+                msg += f'Camera {k} was excluded {int(np.round(v * 100))}% of the time, '
+            elif i == len(named) - 1:
+                msg += f'and Camera {k}: {int(np.round(v * 100))}%.'
+            else:
+                msg += f'Camera {k}: {int(np.round(v * 100))}%, '
+        logging.info(msg)
+        logging.info(f'3D coordinates are stored at {trc_paths[n]}.')
+
+    logging.info('\n\n')
+    if make_c3d:
+        logging.info('All trc files have been converted to c3d.')
+    logging.info(f'Limb swapping was {"handled" if handle_LR_swap else "not handled"}.')
+    logging.info(f'Lens distortions were {"taken into account" if undistort_points else "not taken into account"}.')
