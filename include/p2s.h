@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define P2S_MAX_CAMS 32
-#define P2S_MAX_PERSONS_TOTAL 64   /* association: sum over cameras of detected persons per frame */
+#define P2S_MAX_PERSONS_TOTAL 48   /* association: sum over cameras of detected persons per frame */
 
 #define P2S_OK 0
 #define P2S_ERR_INVALID_ARG (-1)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('P2S_LIB') or os.path.join(_HERE, 'csrc', 'libp2s_hip.
 
 P2S_F32, P2S_F64 = 0, 1
 P2S_MAX_CAMS = 32
-P2S_MAX_PERSONS_TOTAL = 64
+P2S_MAX_PERSONS_TOTAL = 48
 
 
 class TriParams(C.Structure):

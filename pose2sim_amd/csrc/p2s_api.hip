@@ -381,6 +381,82 @@ int p2s_triangulate_host(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32_t
     return P2S_OK;
 }
 
+static int check_assoc(p2s_ctx *ctx, int64_t n_frames, int32_t Kj, int32_t n_max, int32_t dtype,
+                       const p2s_assoc_params *p) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (ctx->n_cams <= 0 || !ctx->full_calib)
+        return fail(P2S_ERR_NO_CALIB, "association needs K, R and T in p2s_set_calibration");
+    if (!p) return fail(P2S_ERR_INVALID_ARG, "null params");
+    if (n_frames < 0 || n_frames > 0x7fffffffLL || Kj <= 0) return fail(P2S_ERR_INVALID_ARG, "bad shape");
+    if (n_max < 1 || n_max > P2S_MAX_PERSONS_TOTAL)
+        return fail(P2S_ERR_INVALID_ARG, "n_max=%d outside [1, %d]", n_max, P2S_MAX_PERSONS_TOTAL);
+    if (dtype != P2S_F32 && dtype != P2S_F64) return fail(P2S_ERR_INVALID_ARG, "dtype must be P2S_F32 or P2S_F64");
+    if (!(p->reconstruction_error_threshold > 0)) return fail(P2S_ERR_INVALID_ARG, "reconstruction_error_threshold must be > 0");
+    if (p->max_iter < 0) return fail(P2S_ERR_INVALID_ARG, "max_iter < 0");
+    return P2S_OK;
+}
+
+int p2s_associate_device(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, int32_t n_max, int32_t dtype,
+                         const int32_t *d_n_persons, const int64_t *d_offsets, const void *d_kpts,
+                         const p2s_assoc_params *params, double *d_affinity) {
+    int rc = check_assoc(ctx, n_frames, n_kpts_json, n_max, dtype, params);
+    if (rc != P2S_OK) return rc;
+    if (n_frames == 0) return P2S_OK;
+    if (!d_n_persons || !d_offsets || !d_kpts || !d_affinity) return fail(P2S_ERR_INVALID_ARG, "null device pointer");
+    if (n_max & 1) return fail(P2S_ERR_INVALID_ARG, "n_max must be even (pad the affinity stride)");
+    P2sAssocArgs a{};
+    a.n_persons = d_n_persons; a.offsets = d_offsets; a.kpts = d_kpts; a.affinity = d_affinity;
+    a.cams = ctx->d_cams;
+    a.n_frames = n_frames; a.C = ctx->n_cams; a.Kj = n_kpts_json; a.Nmax = n_max;
+    a.max_iter = params->max_iter;
+    a.recon_thr = params->reconstruction_error_threshold; a.min_affinity = params->min_affinity;
+    a.w_rank = params->w_rank; a.tol = params->tol; a.w_sparse = params->w_sparse;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(p2s_launch_assoc(a, dtype, ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_associate_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, int32_t n_max, int32_t dtype,
+                       const int32_t *n_persons, const int64_t *offsets, const void *kpts,
+                       const p2s_assoc_params *params, double *affinity) {
+    int rc = check_assoc(ctx, n_frames, n_kpts_json, n_max, dtype, params);
+    if (rc != P2S_OK) return rc;
+    if (n_frames == 0) return P2S_OK;
+    if (!n_persons || !offsets || !affinity) return fail(P2S_ERR_INVALID_ARG, "null host pointer");
+    const int C = ctx->n_cams;
+    // operand shapes are checked on the host before anything is launched
+    int64_t rows = 0;
+    for (int64_t f = 0; f < n_frames; ++f) {
+        if (offsets[f] != rows) return fail(P2S_ERR_INVALID_ARG, "offsets[%lld] does not match n_persons", (long long)f);
+        int64_t nf = 0;
+        for (int c = 0; c < C; ++c) {
+            if (n_persons[f * C + c] < 0) return fail(P2S_ERR_INVALID_ARG, "negative person count");
+            nf += n_persons[f * C + c];
+        }
+        if (nf > n_max) return fail(P2S_ERR_INVALID_ARG, "frame %lld has %lld detections > n_max=%d", (long long)f, (long long)nf, n_max);
+        rows += nf;
+    }
+    if (offsets[n_frames] != rows) return fail(P2S_ERR_INVALID_ARG, "offsets[F] does not match n_persons");
+    if (rows > 0 && !kpts) return fail(P2S_ERR_INVALID_ARG, "null kpts");
+    const size_t elem = dtype == P2S_F32 ? 4 : 8;
+    const size_t kp_bytes = std::max<size_t>(16, (size_t)rows * n_kpts_json * 3 * elem);
+    const size_t aff_bytes = (size_t)n_frames * n_max * n_max * sizeof(double);
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.ensure(kp_bytes)) != P2S_OK) return rc;
+    if ((rc = ctx->aux0.ensure((size_t)n_frames * C * 4)) != P2S_OK) return rc;
+    if ((rc = ctx->aux1.ensure((size_t)(n_frames + 1) * 8)) != P2S_OK) return rc;
+    if ((rc = ctx->q.ensure(aff_bytes)) != P2S_OK) return rc;
+    if (rows > 0) HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, (size_t)rows * n_kpts_json * 3 * elem, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->aux0.p, n_persons, (size_t)n_frames * C * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->aux1.p, offsets, (size_t)(n_frames + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = p2s_associate_device(ctx, n_frames, n_kpts_json, n_max, dtype, (const int32_t *)ctx->aux0.p,
+                              (const int64_t *)ctx->aux1.p, ctx->in.p, params, (double *)ctx->q.p);
+    if (rc != P2S_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(affinity, ctx->q.p, aff_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
 int p2s_timing_begin(p2s_ctx *ctx) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -1,11 +1,286 @@
-// p2s_assoc.hip -- multi-person association kernels (placeholder until the kernels land).
+// p2s_assoc.hip -- multi-person association of every frame on gfx950 (MI355X, CDNA4).
+//
+// One wavefront per frame does the per-frame body of associate_all (personAssociation.py:783-800):
+//
+//   rays      Pluecker coordinates of the camera->keypoint lines (compute_rays, :277-316), staged
+//             in LDS one chunk of joints at a time
+//   affinity  likelihood-weighted mean reciprocal product of every cross-view person pair
+//             (compute_affinity, :347-408) with the circular constraint (:411-428, :794-795)
+//   matchSVT  the ADMM loop of :450-509 entirely in LDS: each iteration thresholds the singular
+//             values of an N x N matrix (SVT, :431-447).  The SVD is a one-sided (Hestenes) Jacobi
+//             SVD in fp64 -- all n/2 column pairs of a round-robin step rotate in parallel, L lanes
+//             per pair, dot products reduced by wave shuffles -- and U diag(max(s-t,0)) V^T is
+//             rebuilt fused with the element-wise update, so the thresholded matrix is never stored
+//   cut       entries below min_affinity are zeroed (:800) and the N x N result goes to HBM; the
+//             order-sensitive proposal extraction (person_index_per_cam, :512-549) stays on the host
+//
+// N = detections of the frame over all cameras (<= P2S_MAX_PERSONS_TOTAL).  Per frame the work is
+// ~10^7 fp64 flops on ~10 KB of input: compute/latency bound, LDS resident, no MFMA (the matrices
+// are 32 x 32 and every step is data dependent).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
 #include "p2s.h"
 #include "p2s_internal.h"
 
-extern "C" {
-int p2s_associate_device(p2s_ctx *, int64_t, int32_t, int32_t, int32_t, const int32_t *, const int64_t *,
-                         const void *, const p2s_assoc_params *, double *) { return P2S_ERR_INVALID_ARG; }
-int p2s_associate_host(p2s_ctx *, int64_t, int32_t, int32_t, int32_t, const int32_t *, const int64_t *,
-                       const void *, const p2s_assoc_params *, double *) { return P2S_ERR_INVALID_ARG; }
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// round-robin (circle method) pairing: step s of n-1, pair k of n/2 -> columns (p, q), n even
+__device__ __forceinline__ void rr_pair(int n, int s, int k, int &p, int &q) {
+    const int m = n - 1;
+    if (k == 0) { p = m; q = s; return; }
+    p = (s + k) % m;
+    q = (s - k + m) % m;
+}
+
+// One-sided Jacobi SVD of the n x n matrix stored column-major in A (column j at A + j*n): on return
+// the columns of A are sigma_j u_j and V (column-major) holds the right singular vectors.
+__device__ void jacobi_svd(double *A, double *V, int n, int lane) {
+    const int npairs = n >> 1;
+    int L = 1;
+    while ((L << 1) * npairs <= 64) L <<= 1;            // lanes per column pair (power of two)
+    const int rpl = (n + L - 1) / L;                    // rows per lane
+    const int k = lane / L, sub = lane - k * L;
+    const bool on = k < npairs;
+    const int r0 = sub * rpl, r1 = min(n, r0 + rpl);
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int s = 0; s < n - 1; ++s) {
+            int p = 0, q = 1;
+            if (on) rr_pair(n, s, k, p, q);
+            double *ap = A + p * n, *aq = A + q * n, *vp = V + p * n, *vq = V + q * n;
+            double al = 0.0, be = 0.0, ga = 0.0;
+            if (on) {
+                for (int r = r0; r < r1; ++r) {
+                    const double x = ap[r], y = aq[r];
+                    al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga);
+                }
+            }
+            for (int off = L >> 1; off > 0; off >>= 1) {
+                al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
+            }
+            const bool rot = on && (fabs(ga) > 1e-15 * sqrt(al * be)) && (ga != 0.0);
+            if (rot) {
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int r = r0; r < r1; ++r) {
+                    const double x = ap[r], y = aq[r];
+                    ap[r] = c * x - sn * y; aq[r] = sn * x + c * y;
+                    const double vx = vp[r], vy = vq[r];
+                    vp[r] = c * vx - sn * vy; vq[r] = sn * vx + c * vy;
+                }
+            }
+            rotated = rotated || rot;
+            lds_fence();
+        }
+        if (!__any(rotated)) break;
+    }
+}
+
+}  // namespace
+
+// LDS (doubles): A[n*n] V[n*n] Y[n*n] X[n*n] W[n*n] wts[n] ; ints: view[n], first[n] (person -> kpts row)
+// the ray chunk aliases A, V, Y while the affinity is being accumulated
+template <typename T>
+__global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_max = a.Nmax;                       // even
+    double *A = reinterpret_cast<double *>(smem);
+    double *V = A + n_max * n_max;
+    double *Y = V + n_max * n_max;
+    double *X = Y + n_max * n_max;
+    double *W = X + n_max * n_max;
+    double *wts = W + n_max * n_max;
+    int *view = reinterpret_cast<int *>(wts + n_max);
+    double *rays = A;                               // [person][joint in chunk][7]
+    const int lane = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int C = a.C, Kj = a.Kj;
+    double *out = a.affinity + f * (int64_t)n_max * n_max;
+
+    // ---- frame layout ---------------------------------------------------------------------
+    int N = 0;
+    for (int c = 0; c < C; ++c) {
+        const int pc = a.n_persons[f * C + c];
+        for (int i = lane; i < pc; i += 64)
+            if (N + i < n_max) view[N + i] = c;
+        N += pc;
+    }
+    N = min(N, n_max);
+    const int n = max(2, (N + 1) & ~1);             // even working size (zero padding)
+    for (int i = lane; i < n * n; i += 64) { X[i] = 0.0; W[i] = 0.0; }
+    for (int i = N + lane; i < n; i += 64) view[i] = -1 - i;   // padding rows: each its own "view"
+    for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
+    lds_fence();
+    if (N == 0) return;
+
+    const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
+    const int n_pairs = N * (N - 1) / 2;
+
+    // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
+    int Kc = (3 * n_max * n_max) / (7 * N);
+    Kc = max(1, min(Kc, Kj));
+    for (int j0 = 0; j0 < Kj; j0 += Kc) {
+        const int kc = min(Kc, Kj - j0);
+        for (int it = lane; it < N * kc; it += 64) {          // compute_rays (:293-314)
+            const int i = it / kc, j = it - i * kc;
+            const P2sCam &cam = a.cams[view[i]];
+            const T *o = kp + ((int64_t)i * Kj + j0 + j) * 3;
+            const double x = (double)o[0], y = (double)o[1], lik = (double)o[2];
+            const double v0 = cam.iK[0] * x + cam.iK[1] * y + cam.iK[2] - cam.T[0];
+            const double v1 = cam.iK[3] * x + cam.iK[4] * y + cam.iK[5] - cam.T[1];
+            const double v2 = cam.iK[6] * x + cam.iK[7] * y + cam.iK[8] - cam.T[2];
+            const double l0 = cam.R[0] * v0 + cam.R[3] * v1 + cam.R[6] * v2 - cam.center[0];
+            const double l1 = cam.R[1] * v0 + cam.R[4] * v1 + cam.R[7] * v2 - cam.center[1];
+            const double l2 = cam.R[2] * v0 + cam.R[5] * v1 + cam.R[8] * v2 - cam.center[2];
+            const double nrm = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+            double d0 = l0 / nrm, d1 = l1 / nrm, d2 = l2 / nrm;
+            double m0 = cam.center[1] * d2 - cam.center[2] * d1;
+            double m1 = cam.center[2] * d0 - cam.center[0] * d2;
+            double m2 = cam.center[0] * d1 - cam.center[1] * d0;
+            double lk = lik;
+            const bool anynan = !(d0 == d0) || !(d1 == d1) || !(d2 == d2) || !(m0 == m0) || !(m1 == m1) ||
+                                !(m2 == m2) || !(lk == lk);
+            if (anynan) { d0 = d1 = d2 = m0 = m1 = m2 = lk = 0.0; }
+            double *r = rays + ((size_t)i * kc + j) * 7;
+            r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1; r[5] = m2; r[6] = lk;
+        }
+        lds_fence();
+        for (int pr = lane; pr < n_pairs; pr += 64) {         // compute_affinity (:383-394)
+            // pair index -> (i, l), i < l
+            int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)pr)) * 0.5);
+            while (i * (i - 1) / 2 > pr) --i;
+            while ((i + 1) * i / 2 <= pr) ++i;
+            const int l = i, ii = pr - i * (i - 1) / 2;       // ii < l
+            if (view[ii] == view[l]) continue;
+            const double *r0 = rays + (size_t)ii * kc * 7, *r1 = rays + (size_t)l * kc * 7;
+            double num = 0.0, den = 0.0;
+            for (int j = 0; j < kc; ++j) {
+                const double *p0 = r0 + j * 7, *p1 = r1 + j * 7;
+                const double prod = (p0[0] * p1[3] + p0[1] * p1[4] + p0[2] * p1[5]) +
+                                    (p1[0] * p0[3] + p1[1] * p0[4] + p1[2] * p0[5]);
+                const double lk = sqrt(p0[6] * p1[6]);
+                num = fma(fabs(prod), lk, num);
+                den += lk;
+            }
+            X[ii * n + l] += num;
+            W[ii * n + l] += den;
+        }
+        lds_fence();
+    }
+    // distance -> affinity (:397-406), circular constraint (:794-795), matchSVT initialisation (:467-475)
+    const double thr = a.recon_thr;
+    for (int pr = lane; pr < n * n; pr += 64) {
+        const int i = pr / n, l = pr - i * n;
+        if (i >= l) continue;
+        double aff = 0.0;
+        if (i < N && l < N && view[i] != view[l]) {
+            double d = X[i * n + l] / (1e-5 + W[i * n + l]);
+            d = d > thr ? thr : d;                           // NaN stays NaN like the reference's comparison
+            aff = 1.0 - d / thr;
+        }
+        X[i * n + l] = aff; X[l * n + i] = aff;
+        W[i * n + l] = a.w_sparse - aff; W[l * n + i] = a.w_sparse - aff;
+    }
+    for (int i = lane; i < n; i += 64) { X[i * n + i] = 0.0; W[i * n + i] = a.w_sparse; }
+    for (int i = lane; i < n * n; i += 64) Y[i] = 0.0;
+    lds_fence();
+
+    // ---- matchSVT (:477-505) --------------------------------------------------------------
+    double mu = 64.0;
+    for (int iter = 0; iter < a.max_iter; ++iter) {
+        // SVT input X + Y/mu (:480), stored column-major for the column rotations; V = I
+        for (int i = lane; i < n * n; i += 64) {
+            const int r = i / n, c = i - r * n;
+            A[c * n + r] = X[i] + Y[i] * 1.0 / mu;
+            V[i] = (r == c) ? 1.0 : 0.0;
+        }
+        lds_fence();
+        jacobi_svd(A, V, n, lane);
+        const double tsv = a.w_rank / mu;
+        for (int j = lane; j < n; j += 64) {
+            double s2 = 0.0;
+            for (int r = 0; r < n; ++r) s2 = fma(A[j * n + r], A[j * n + r], s2);
+            const double sg = sqrt(s2);
+            wts[j] = (sg > tsv) ? (sg - tsv) / sg : 0.0;
+        }
+        lds_fence();
+        double pres2 = 0.0, dres2 = 0.0;
+        for (int pr = lane; pr < n * (n + 1) / 2; pr += 64) {
+            int l = (int)((sqrt(1.0 + 8.0 * (double)pr) - 1.0) * 0.5);
+            while (l * (l + 1) / 2 > pr) --l;
+            while ((l + 1) * (l + 2) / 2 <= pr) ++l;
+            const int i = pr - l * (l + 1) / 2;               // i <= l
+            if (l >= N) continue;                             // zero padding is not part of the problem
+            double q_il = 0.0, q_li = 0.0;                    // SVT (:443-445): U diag(max(s-t,0)) Vt
+            for (int j = 0; j < n; ++j) {
+                const double w = wts[j];
+                q_il = fma(w * A[j * n + i], V[j * n + l], q_il);
+                q_li = fma(w * A[j * n + l], V[j * n + i], q_li);
+            }
+            const bool same_view = view[i] == view[l];
+            double x_il = q_il - (W[i * n + l] + Y[i * n + l]) / mu;   // :482
+            double x_li = q_li - (W[l * n + i] + Y[l * n + i]) / mu;
+            if (same_view) { x_il = 0.0; x_li = 0.0; }        // :485-487
+            if (i == l) { x_il = 1.0; x_li = 1.0; }           // :490
+            x_il = x_il < 0.0 ? 0.0 : x_il; x_il = x_il > 1.0 ? 1.0 : x_il;   // :491-492
+            x_li = x_li < 0.0 ? 0.0 : x_li; x_li = x_li > 1.0 ? 1.0 : x_li;
+            const double cc = (same_view && i != l) ? 0.0 : 1.0;              // :495
+            x_il *= cc; x_li *= cc;
+            const double sym = (x_il + x_li) / 2;             // :496
+            const double old_il = X[i * n + l], old_li = X[l * n + i];
+            Y[i * n + l] = Y[i * n + l] + mu * (sym - q_il);  // :497
+            pres2 += (sym - q_il) * (sym - q_il);
+            dres2 += (sym - old_il) * (sym - old_il);
+            if (i != l) {
+                Y[l * n + i] = Y[l * n + i] + mu * (sym - q_li);
+                pres2 += (sym - q_li) * (sym - q_li);
+                dres2 += (sym - old_li) * (sym - old_li);
+            }
+            X[i * n + l] = sym; X[l * n + i] = sym;
+        }
+        lds_fence();
+        const double pRes = sqrt(wave_sum(pres2)) / (double)N;          // :500
+        const double dRes = mu * sqrt(wave_sum(dres2)) / (double)N;     // :501
+        if (pRes < a.tol && dRes < a.tol) break;                        // :502
+        if (pRes > 10 * dRes) mu = 2 * mu;                              // :504
+        else if (dRes > 10 * pRes) mu = mu / 2;                         // :505
+    }
+    // ---- min_affinity cut (:800) and store ----------------------------------------------------
+    for (int pr = lane; pr < N * N; pr += 64) {
+        const int i = pr / N, l = pr - i * N;
+        const double v = X[i * n + l];
+        out[i * n_max + l] = (v < a.min_affinity) ? 0.0 : v;
+    }
+}
+
+hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
+    const size_t lds = (size_t)(5 * a.Nmax * a.Nmax + a.Nmax) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
+    hipError_t e;
+    if (dtype == P2S_F32) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_assoc_kernel<float>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((p2s_assoc_kernel<float>), dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_assoc_kernel<double>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((p2s_assoc_kernel<double>), dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
+    }
+    return hipGetLastError();
 }

@@ -133,3 +133,36 @@ class Engine:
         fb, th, lds = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self._lib.p2s_tri_geometry(self.n_cams, int(K), int(dtype), C.byref(fb), C.byref(th), C.byref(lds)))
         return {'blocks_per_tile': fb.value, 'threads': th.value, 'lds_bytes': lds.value}
+
+    # -- association -----------------------------------------------------------------------
+    @staticmethod
+    def assoc_params(recon_thr, min_affinity, min_cams, max_iter=20, w_rank=50.0, tol=1e-4, w_sparse=0.1):
+        """matchSVT constants are the reference's call-site values (personAssociation.py:799)."""
+        return AssocParams(float(recon_thr), float(min_affinity), int(min_cams), int(max_iter), float(w_rank),
+                           float(tol), float(w_sparse))
+
+    def associate(self, n_persons, kpts, params):
+        """n_persons [F][C] int, kpts [rows][Kj][3] (camera-major then person, JSON keypoint order).
+        Returns the thresholded matchSVT matrices [F][n_max][n_max] (top-left N_f x N_f valid)."""
+        n_persons = np.ascontiguousarray(np.asarray(n_persons, dtype=np.int32))
+        F, Cn = n_persons.shape
+        if Cn != self.n_cams:
+            raise P2sError(f'n_persons has {Cn} cameras; calibration has {self.n_cams}')
+        kpts, dtype = as_packed(kpts)
+        per_frame = n_persons.sum(axis=1, dtype=np.int64)
+        offsets = np.zeros(F + 1, dtype=np.int64)
+        np.cumsum(per_frame, out=offsets[1:])
+        if kpts.ndim != 3 or kpts.shape[0] != offsets[-1] or kpts.shape[2] != 3:
+            raise P2sError(f'kpts has shape {kpts.shape}; expected [{offsets[-1]}, Kj, 3]')
+        n_max = int(per_frame.max()) if F else 0
+        n_max = max(2, (n_max + 1) & ~1)
+        aff = np.zeros((F, n_max, n_max), dtype=np.float64)
+        _lib.check(self._lib.p2s_associate_host(self._h, F, kpts.shape[1], n_max, dtype, _ptr(n_persons),
+                                                _ptr(offsets), _ptr(kpts) if kpts.size else None, C.byref(params),
+                                                _ptr(aff)))
+        return aff
+
+    def associate_device(self, F, Kj, n_max, dtype, d_n_persons, d_offsets, d_kpts, params, d_aff):
+        _lib.check(self._lib.p2s_associate_device(self._h, int(F), int(Kj), int(n_max), int(dtype),
+                                                  _ptr(d_n_persons), _ptr(d_offsets), _ptr(d_kpts),
+                                                  C.byref(params), _ptr(d_aff)))

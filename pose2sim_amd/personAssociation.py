@@ -1,0 +1,180 @@
+"""Person association stage: drop-in for the reference's ``associate_all(config_dict)``
+(personAssociation.py:642-808), multi-person branch, with rays + affinity + matchSVT on the MI355X.
+
+Per frame the reference computes Pluecker rays, the pairwise epipolar affinity, ~20 full SVDs
+(matchSVT) and then extracts proposals; here every frame of the trial goes to the HIP engine in ONE
+call and only the order-sensitive proposal extraction (person_index_per_cam, :512-549, exact
+``np.unique`` / ``argsort`` semantics) and the JSON rewrite (:552-580) stay on the host.
+
+The single-person branch (brute-force person x camera-subset search on one tracked keypoint,
+:67-257) is not part of this engine yet ("next").
+"""
+import json
+import logging
+import os
+
+import numpy as np
+
+from . import calib as calib_mod
+from . import poseio, skeletons
+from ._lib import P2S_MAX_PERSONS_TOTAL
+
+
+def _make_engine():
+    from .engine import Engine
+    return Engine(int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def person_index_per_cam(affinity, cum_persons_per_view, min_cameras_for_triangulation):
+    """personAssociation.py:512-549.  Row order of the result = person order in the rewritten JSON."""
+    n_views = len(cum_persons_per_view) - 1
+    rows = []
+    for r in range(affinity.shape[0]):
+        row = []
+        for cam in range(n_views):
+            block = affinity[r, cum_persons_per_view[cam]:cum_persons_per_view[cam + 1]]
+            row += [np.argmax(block) if (len(block) > 0 and max(block) > 0) else -1]
+        rows.append(row)
+    proposals = np.array(rows, dtype=float)
+    if proposals.size == 0:
+        return np.array([])
+    proposals, nb_detections = np.unique(proposals, axis=0, return_counts=True)
+    proposals = proposals[np.argsort(nb_detections)[::-1]]
+    proposals[proposals == -1] = np.nan
+    mask = np.ones(proposals.shape[0], dtype=bool)
+    for i in range(1, len(proposals)):
+        mask[i] = ~np.any(proposals[i] == proposals[:i], axis=0).any()
+    proposals = proposals[mask]
+    nb_cams_per_person = [np.count_nonzero(~np.isnan(p)) for p in proposals]
+    return np.array([p for (n, p) in zip(nb_cams_per_person, proposals) if n >= min_cameras_for_triangulation])
+
+
+def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
+    """personAssociation.py:552-580: people reordered by proposal, {} where a camera does not see
+    the person; an unreadable source leaves no output file."""
+    for cam in range(n_cams):
+        try:
+            with open(json_tracked_files_f[cam], 'w') as json_tracked_f:
+                with open(json_files_f[cam], 'r') as json_f:
+                    js = json.load(json_f)
+                    js_new = js.copy()
+                    js_new['people'] = []
+                    for new_comb in proposals:
+                        if not np.isnan(new_comb[cam]):
+                            js_new['people'] += [js['people'][int(new_comb[cam])]]
+                        else:
+                            js_new['people'] += [{}]
+                json_tracked_f.write(json.dumps(js_new))
+        except Exception:
+            os.remove(json_tracked_files_f[cam])
+
+
+def recap_tracking(config_dict):
+    """Multi-person lines of personAssociation.py:583-639."""
+    project_dir = config_dict.get('project').get('project_dir')
+    reconstruction_error_threshold = config_dict.get('personAssociation').get('multi_person').get('reconstruction_error_threshold')
+    min_affinity = config_dict.get('personAssociation').get('multi_person').get('min_affinity')
+    poseTracked_dir = os.path.join(project_dir, 'pose-associated')
+    logging.info(f'\n--> A person was reconstructed if the lines from cameras to their keypoints intersected within {reconstruction_error_threshold} m and if the calculated affinity stayed above {min_affinity}.')
+    logging.info('--> Beware that people were sorted across cameras, but not across frames. This will be done in the triangulation stage.')
+    logging.info(f'\nTracked json files are stored in {os.path.realpath(poseTracked_dir)}.')
+
+
+def associate_all(config_dict):
+    """Same contract as the reference: reads <project>/pose/<cam>_json, writes
+    <project>/pose-associated/<cam>_json with the people of every file reordered consistently
+    across cameras."""
+    project_dir = config_dict.get('project').get('project_dir')
+    session_dir = os.path.realpath(os.path.join(project_dir, '..'))
+    session_dir = session_dir if 'Config.toml' in os.listdir(session_dir) else os.getcwd()
+    multi_person = config_dict.get('project').get('multi_person')
+    pose_model = config_dict.get('pose').get('pose_model')
+    min_cameras_for_triangulation = config_dict.get('triangulation').get('min_cameras_for_triangulation')
+    reconstruction_error_threshold = config_dict.get('personAssociation').get('multi_person').get('reconstruction_error_threshold')
+    min_affinity = config_dict.get('personAssociation').get('multi_person').get('min_affinity')
+    frame_range = config_dict.get('project').get('frame_range')
+    undistort_points = config_dict.get('triangulation').get('undistort_points')
+
+    calib_file = calib_mod.find_calibration_file(session_dir)
+    pose_dir = os.path.join(project_dir, 'pose')
+    poseSync_dir = os.path.join(project_dir, 'pose-sync')
+    poseTracked_dir = os.path.join(project_dir, 'pose-associated')
+
+    P_all = calib_mod.computeP(calib_file, undistort=undistort_points)
+    calib_params = calib_mod.retrieve_calib_params(calib_file)
+    skeletons.model_rows(pose_model, config_dict)          # NameError for an unknown model, like :695-711
+
+    pose_listdirs_names = next(os.walk(pose_dir))[1]
+    try:
+        pose_listdirs_names = poseio.sort_stringlist_by_last_number(pose_listdirs_names)
+        os.listdir(os.path.join(pose_dir, pose_listdirs_names[0]))[0]
+    except Exception:
+        raise ValueError(f'No json files found in {pose_dir} subdirectories. Make sure you run Pose2Sim.poseEstimation() first.')
+    json_dirs_names = [k for k in pose_listdirs_names if 'json' in k]
+    try:
+        json_files_names = poseio.list_json_files(poseSync_dir, json_dirs_names)
+    except Exception:
+        try:
+            json_files_names = poseio.list_json_files(pose_dir, json_dirs_names)
+        except Exception:
+            raise ValueError(f'No json files found in {pose_dir} nor {poseSync_dir} subdirectories. Make sure you run Pose2Sim.poseEstimation() first.')
+
+    if not os.path.exists(poseTracked_dir):
+        os.mkdir(poseTracked_dir)
+    try:
+        [os.mkdir(os.path.join(poseTracked_dir, k)) for k in json_dirs_names]
+    except Exception:
+        pass
+
+    f_range = [[0, max([len(j) for j in json_files_names])] if frame_range in ('all', 'auto', []) else frame_range][0]   # max, :736
+    n_cams = len(json_dirs_names)
+    if n_cams != len(P_all):
+        raise Exception(f'Error: The number of cameras is not consistent:\
+                    Found {len(P_all)} cameras in the calibration file,\
+                    and {n_cams} cameras based on the number of pose folders.')
+
+    if not multi_person:
+        logging.info('\nSingle-person analysis selected.')
+        raise NotImplementedError('single-person association (personAssociation.py:67-257) is not part of this '
+                                  'engine yet; set project.multi_person = true or run that mode with the reference.')
+    logging.info('\nMulti-person analysis selected.')
+
+    # ---- read every frame (always from pose/: the reference's os.path.exist typo at :764) --------
+    maps = poseio.frame_file_map(json_files_names)
+    frames = range(*f_range)
+    src_files, dst_files, people_all = [], [], []
+    n_persons = np.zeros((len(frames), n_cams), dtype=np.int32)
+    Kj3 = None
+    for fi, f in enumerate(frames):
+        names = [maps[c].get(f, 'none') for c in range(n_cams)]
+        src = [os.path.join(pose_dir, json_dirs_names[c], names[c]) for c in range(n_cams)]
+        dst = [os.path.join(poseTracked_dir, json_dirs_names[c], names[c]) for c in range(n_cams)]
+        src_files.append(src)
+        dst_files.append(dst)
+        for c in range(n_cams):
+            people = poseio.read_people(src[c])
+            n_persons[fi, c] = len(people)
+            for p in people:
+                if Kj3 is None:
+                    Kj3 = len(p)
+                if len(p) != Kj3 or Kj3 % 3:
+                    raise ValueError(f'{src[c]}: every person must carry the same number of keypoint triplets')
+                people_all.append(p)
+    if n_persons.sum(axis=1).max(initial=0) > P2S_MAX_PERSONS_TOTAL:
+        raise ValueError(f'a frame holds more than {P2S_MAX_PERSONS_TOTAL} detections over all cameras')
+    Kj = (Kj3 or 3) // 3
+    kpts = np.asarray(people_all, dtype=np.float64).reshape(-1, Kj, 3)
+
+    # ---- rays, affinity and matchSVT of every frame: one call into the HIP engine ------------------
+    engine = _make_engine()
+    engine.set_calibration(P_all, calib_params)
+    prm = engine.assoc_params(reconstruction_error_threshold, min_affinity, min_cameras_for_triangulation)
+    affinity = engine.associate(n_persons, kpts, prm)
+
+    for fi in range(len(frames)):
+        cum = np.cumsum([0] + list(n_persons[fi]))
+        N = int(cum[-1])
+        proposals = person_index_per_cam(affinity[fi, :N, :N], cum, min_cameras_for_triangulation)
+        rewrite_json_files(dst_files[fi], src_files[fi], proposals, n_cams)
+
+    recap_tracking(config_dict)
