@@ -34,6 +34,10 @@ CONFIGS = {
                        F=100_000, C=8, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
                        undistort=False, lr_swap=False, seed=2,
                        gen=dict(p_lowlik=0.0, p_outlier=0.0, p_missing_cam=0.0)),
+    # BASELINE configs[2]: multi-person association (its own metric: frames/s)
+    'cfg3': dict(workload='Demo_MultiPerson-style: 8 cams x 4 persons x HALPE_26 x 50k frames, epipolar association (BASELINE configs[2])',
+                 F=50_000, C=8, model='HALPE_26', Pn=4, thr=15.0, lik=0.3, min_cams=2,
+                 undistort=False, lr_swap=False, seed=3, assoc=True),
     # per-GPU shard of BASELINE configs[3] (1M frames over 8 GPUs)
     'cfg4': dict(workload='synthetic 16-cam x COCO_133 (131 kpts) x 125k frames/GPU, min_cameras=3 (BASELINE configs[3] shard)',
                  F=125_000, C=16, model='COCO_133', Pn=1, thr=15.0, lik=0.3, min_cams=3,
@@ -64,6 +68,92 @@ def make_workload(cfg, rank):
     xyl = np.concatenate(chunks, axis=0)
     P = synth.projection_matrices(cams, cfg['undistort'])
     return xyl, cams, P, np.asarray(swap, dtype=np.int32), K
+
+
+def make_association_inputs(xyl, seed):
+    """Per (frame, camera): persons in random order, 2 % of them undetected.
+    -> n_persons i32 [F][C], kpts f32 [rows][K][3] (camera-major, then person)."""
+    rng = np.random.default_rng(seed + 5000)
+    F, Pn, C, K, _ = xyl.shape
+    keys = rng.random((F, C, Pn))
+    keys[rng.random((F, C, Pn)) < 0.02] = 2.0                      # undetected -> sorted last, dropped
+    order = np.argsort(keys, axis=2)
+    kept = np.take_along_axis(keys, order, axis=2) < 1.5
+    per_cam = xyl.transpose(0, 2, 1, 3, 4)                         # [F][C][Pn][K][3]
+    gathered = np.take_along_axis(per_cam, order[..., None, None], axis=2)
+    gathered = np.nan_to_num(gathered, nan=0.0)                    # a pose estimator writes zeros, not NaN
+    return kept.sum(axis=2).astype(np.int32), np.ascontiguousarray(gathered[kept])
+
+
+def bench_association(args, cfg, rank, world, local_rank):
+    import torch
+    import torch.distributed as dist
+    from pose2sim_amd.engine import Engine, P2S_F32
+    xyl, cams, P, swap, K = make_workload(cfg, rank)
+    n_persons, kpts = make_association_inputs(xyl, cfg['seed'] + rank)
+    F, C = n_persons.shape
+    per_frame = n_persons.sum(axis=1, dtype=np.int64)
+    offsets = np.zeros(F + 1, dtype=np.int64)
+    np.cumsum(per_frame, out=offsets[1:])
+    n_max = max(2, (int(per_frame.max()) + 1) & ~1)
+    dev = torch.device('cuda', local_rank)
+    eng = Engine(local_rank)
+    eng.set_calibration(P, cams)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    prm = Engine.assoc_params(0.1, 0.2, cfg['min_cams'])
+    d_np = torch.from_numpy(n_persons).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    d_kp = torch.from_numpy(kpts).to(dev)
+    d_aff = torch.empty((F, n_max, n_max), dtype=torch.float64, device=dev)
+
+    def step():
+        eng.associate_device(F, K, n_max, P2S_F32, d_np, d_off, d_kp, prm, d_aff)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    out = {'metric': 'association-frames/sec', 'value': F * world * args.steps / dt, 'unit': 'frames/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': cfg['workload'], 'frames_per_gpu': F, 'cams': C, 'kpts_json': K,
+                      'detections_per_frame_max': n_max, 'detections_per_frame_mean': float(per_frame.mean()),
+                      'parallelism': f'frame shards x{world}'},
+           'roofline': {'bound': 'mfma', 'achieved': None, 'peak': None, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None,
+                        'note': 'latency/compute-bound LDS-resident fp64 Jacobi loop; HBM and MFMA fractions are not meaningful (SURVEY 8d)'}}
+    if not args.no_cpu_baseline:
+        from oracle import association_ref as ar
+        cal = {'inv_K': cams['inv_K'], 'R_mat': cams['R_mat'], 'T': cams['T']}
+        nfr = args.cpu_frames or 300
+        t0 = time.perf_counter()
+        row = 0
+        for f in range(nfr):
+            per_cam = []
+            for c in range(C):
+                per_cam.append([kpts[row + i].astype(np.float64).ravel() for i in range(n_persons[f, c])])
+                row += n_persons[f, c]
+            ar.associate_frame(per_cam, cal, 0.1, 0.2, cfg['min_cams'])
+        cdt = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': nfr / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'first {nfr} frames of the same workload ({cdt:.1f} s), NumPy oracle incl. proposal extraction'}
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(cfg, xyl, cams, P, swap, budget_frames):
@@ -112,6 +202,11 @@ def main():
     from pose2sim_amd.engine import Engine, P2S_F32
 
     cfg = CONFIGS[args.config]
+    if cfg.get('assoc'):
+        bench_association(args, cfg, rank, world, local_rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     xyl, cams, P, swap, K = make_workload(cfg, rank)
     F, Pn, C = xyl.shape[0], xyl.shape[1], xyl.shape[2]
     n_blocks = F * Pn
@@ -201,7 +296,7 @@ def main():
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'p2s_tri_kernel', 'kernel_ms': k_ms,
+                         'kernel': 'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }
         if not args.no_cpu_baseline and world == 1:
