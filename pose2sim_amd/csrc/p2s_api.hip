@@ -69,6 +69,8 @@ struct p2s_ctx {
     int n_cams = 0;
     bool full_calib = false;     // K, dist, R, T, newK were provided
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side_stream = nullptr;               // search kernels run here, beside the next chunk's streaming pass
+    hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
     Scratch in, swap, q, err, nexcl, mask, aux0, aux1;
     Scratch wl_rec, wl_count;
 };
@@ -115,7 +117,7 @@ Geometry choose_geometry(int C, int K, int dtype) {
     return best;
 }
 
-constexpr int64_t kChunkUnits = 1 << 21;   // units per (level-0, search) kernel pair: bounds the work-list scratch
+constexpr int64_t kChunkUnits = 1 << 22;   // units per (level-0, search) kernel pair: bounds the work-list scratch
 
 void fill_binom(uint32_t *b) {
     for (int n = 0; n < 33; ++n)
@@ -186,6 +188,11 @@ int p2s_create(int device_id, p2s_ctx **out) {
     HIP_TRY(hipMemcpy(c->d_binom, b.data(), b.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_k1[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_k2[i], hipEventDisableTiming));
+    }
     *out = c;
     return P2S_OK;
 }
@@ -202,6 +209,11 @@ int p2s_destroy(p2s_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_k1[i]) (void)hipEventDestroy(ctx->ev_k1[i]);
+        if (ctx->ev_k2[i]) (void)hipEventDestroy(ctx->ev_k2[i]);
+    }
     delete ctx;
     return P2S_OK;
 }
@@ -341,7 +353,16 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         L.grid1 = (int)((waves + wpb - 1) / wpb);
         L.threads1 = 64 * wpb;
         L.lds1 = lds1;
-        HIP_TRY(p2s_launch_tri(a, dtype, L, ctx->stream));
+        const int slot = (int)(ch & 1);
+        const bool overlap = n_chunks > 1 && !getenv("P2S_NO_OVERLAP");
+        hipStream_t side = overlap ? ctx->side_stream : ctx->stream;
+        if (overlap && ch >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[slot], 0));   // list `slot` is free again
+        HIP_TRY(p2s_launch_tri(a, dtype, L, ctx->stream, side, ctx->ev_k1[slot]));
+        if (overlap) HIP_TRY(hipEventRecord(ctx->ev_k2[slot], side));
+    }
+    if (n_chunks > 1 && !getenv("P2S_NO_OVERLAP")) {   // join: the caller's stream sees every search finished
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[(n_chunks - 1) & 1], 0));
+        if (n_chunks > 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[(n_chunks - 2) & 1], 0));
     }
     return P2S_OK;
 }

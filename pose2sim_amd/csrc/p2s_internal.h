@@ -60,7 +60,8 @@ struct P2sAssocArgs {
     double recon_thr, min_affinity, w_rank, tol, w_sparse;
 };
 
-hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s);
+hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
+                          hipEvent_t k1_done);
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s);
 
 #endif

@@ -282,14 +282,14 @@ __device__ __forceinline__ double fast_rsqrt(double t) {
 
 // Reprojection distance of one camera (common.py:357-403).  With a = P0.Q, b = P1.Q, z = P2.Q:
 // |(a/z - x, b/z - y)| = s / sqrt(s z^2), s = (a - x z)^2 + (b - y z)^2: one reciprocal square
-// root instead of a division and a square root.  Degenerate or NaN operands (s z^2 not in (0, inf))
-// take the literal formula with the reference's NaN rules; `wanted` keeps cameras whose distance is
-// not used from dragging the wave onto that path.
+// root instead of a division and a square root.  `regular` is false for degenerate or NaN operands
+// (s z^2 not in (0, inf)); those are redone by camera_distance_exact.
 template <bool UNDISTORT>
-__device__ __forceinline__ double camera_distance(cam_cptr cam, const double q[3], double x, double y, bool wanted) {
+__device__ __forceinline__ double camera_distance(cam_cptr cam, const double q[3], double x, double y, bool &regular) {
     if (UNDISTORT) {
         double u, v;
         project_distorted(cam, q, u, v);
+        regular = true;
         return pair_distance(u - x, v - y);
     }
     const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
@@ -298,14 +298,17 @@ __device__ __forceinline__ double camera_distance(cam_cptr cam, const double q[3
     const double dxz = fma(-x, z, a), dyz = fma(-y, z, b);
     const double s = fma(dxz, dxz, dyz * dyz);
     const double t = s * z * z;
-    double d = s * fast_rsqrt(t);
-    const bool regular = (t > 0.0) && (t < kInf);
-    if (__any(wanted && !regular)) {
-        const double rz = fast_rcp(z);
-        const double slow = pair_distance(a * rz - x, b * rz - y);
-        d = regular ? d : slow;
-    }
-    return d;
+    regular = (t > 0.0) && (t < kInf);
+    return s * fast_rsqrt(t);
+}
+
+// The literal formula with the reference's NaN rules (all-NaN difference -> inf, nansum).
+__device__ __noinline__ double camera_distance_exact(cam_cptr cam, const double q[3], double x, double y) {
+    const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
+    const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], fma(cam->P[6], q[2], cam->P[7])));
+    const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], fma(cam->P[10], q[2], cam->P[11])));
+    const double rz = fast_rcp(z);
+    return pair_distance(a * rz - x, b * rz - y);
 }
 
 // Mean reprojection error over the cameras of `kept` (triangulation.py:472-489).
@@ -313,13 +316,26 @@ template <typename T, bool UNDISTORT>
 __device__ __forceinline__ double mean_error(cam_cptr cams, int C, const UnitObs<T> &o, uint32_t kept,
                                              const double q[3]) {
     double sum = 0.0;
+    bool irregular = false;
 #pragma unroll 2
     for (int c = 0; c < C; ++c) {
         double x, y, w;
         o.raw(c, x, y, w);
         const bool k = (kept >> c) & 1u;
-        const double d = camera_distance<UNDISTORT>(cams + c, q, x, y, k);
+        bool reg;
+        const double d = camera_distance<UNDISTORT>(cams + c, q, x, y, reg);
+        irregular = irregular || (k && !reg);
         sum += k ? d : 0.0;
+    }
+    if (__any(irregular)) {                        // rare: some wanted camera is degenerate / NaN
+        double sum2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            double x, y, w;
+            o.raw(c, x, y, w);
+            const double d = camera_distance_exact(cams + c, q, x, y);
+            sum2 += ((kept >> c) & 1u) ? d : 0.0;
+        }
+        sum = irregular ? sum2 : sum;
     }
     return sum * fast_rcp((double)__popc(kept));   // no camera kept -> NaN, as np.mean([])
 }
@@ -345,14 +361,30 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const Uni
     }
     smallest_eigvec(Nw, qs);
     double sum = 0.0;
+    bool irregular = false;
     taken = 0;
     for (int c = 0; c < C; ++c) {
         double xs, ys;
         osw.masked_xy(c, xs, ys);
         const bool k = ((kept >> c) & 1u) && taken < M;
-        const double d = camera_distance<UNDISTORT>(cams + c, qs, xs, ys, k);
+        bool reg;
+        const double d = camera_distance<UNDISTORT>(cams + c, qs, xs, ys, reg);
+        irregular = irregular || (k && !reg);
         sum += k ? d : 0.0;
         taken += ((kept >> c) & 1u) ? 1 : 0;
+    }
+    if (__any(irregular)) {
+        double sum2 = 0.0;
+        taken = 0;
+        for (int c = 0; c < C; ++c) {
+            double xs, ys;
+            osw.masked_xy(c, xs, ys);
+            const bool k = ((kept >> c) & 1u) && taken < M;
+            const double d = camera_distance_exact(cams + c, qs, xs, ys);
+            sum2 += k ? d : 0.0;
+            taken += ((kept >> c) & 1u) ? 1 : 0;
+        }
+        sum = irregular ? sum2 : sum;
     }
     return sum * fast_rcp((double)M);
 }
@@ -725,8 +757,11 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel 1 goes to the main stream, kernel 2 to the side stream behind an event, so that the search
+// of one chunk runs beside the streaming pass of the next.
 template <typename T, bool U, bool L>
-static hipError_t launch_both(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s) {
+static hipError_t launch_both(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
+                              hipEvent_t k1_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_level0_kernel<T, U, L>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds0);
     if (e != hipSuccess) return e;
@@ -737,16 +772,22 @@ static hipError_t launch_both(const P2sTriArgs &a, const P2sTriLaunch &g, hipStr
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.debug_mode == 1) return hipSuccess;
-    hipLaunchKernelGGL((p2s_tri_search_kernel<T, U, L>), dim3(g.grid1), dim3(g.threads1), g.lds1, s, a);
+    if (side != s) {
+        if ((e = hipEventRecord(k1_done, s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(side, k1_done, 0)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((p2s_tri_search_kernel<T, U, L>), dim3(g.grid1), dim3(g.threads1), g.lds1, side, a);
     return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t launch_t(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s) {
-    if (a.undistort) return a.lr_swap ? launch_both<T, true, true>(a, g, s) : launch_both<T, true, false>(a, g, s);
-    return a.lr_swap ? launch_both<T, false, true>(a, g, s) : launch_both<T, false, false>(a, g, s);
+static hipError_t launch_t(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s, hipStream_t side, hipEvent_t ev) {
+    if (a.undistort)
+        return a.lr_swap ? launch_both<T, true, true>(a, g, s, side, ev) : launch_both<T, true, false>(a, g, s, side, ev);
+    return a.lr_swap ? launch_both<T, false, true>(a, g, s, side, ev) : launch_both<T, false, false>(a, g, s, side, ev);
 }
 
-hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s) {
-    return dtype == 0 ? launch_t<float>(a, g, s) : launch_t<double>(a, g, s);
+hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
+                          hipEvent_t k1_done) {
+    return dtype == 0 ? launch_t<float>(a, g, s, side, k1_done) : launch_t<double>(a, g, s, side, k1_done);
 }
