@@ -306,7 +306,10 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     // the work list: P2S_WL_SHARDS shards, workgroup b of the streaming kernel appends to shard b % SHARDS;
     // two lists are used alternately by consecutive chunks; counters are zeroed on the stream first
     const int64_t tiles_per_chunk = chunk_blocks / g.FB;
-    const int64_t shard_cap = (tiles_per_chunk + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * (int64_t)g.FB * n_kpts;
+    const int64_t shard_cap_tiled = (tiles_per_chunk + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * (int64_t)g.FB * n_kpts;
+    const int64_t direct_wgs = (chunk_units + 255) / 256;     // the direct kernel appends per 256-unit workgroup
+    const int64_t shard_cap_direct = (direct_wgs + P2S_WL_SHARDS - 1) / P2S_WL_SHARDS * 256;
+    const int64_t shard_cap = std::max(shard_cap_tiled, shard_cap_direct);
     const size_t list_bytes = (size_t)P2S_WL_SHARDS * shard_cap * rec_bytes;
     if ((rc = ctx->wl_rec.ensure(2 * list_bytes)) != P2S_OK) return rc;
     if ((rc = ctx->wl_count.ensure((size_t)n_chunks * 2 * P2S_WL_SHARDS * sizeof(uint32_t))) != P2S_OK) return rc;
@@ -353,6 +356,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         L.grid1 = (int)((waves + wpb - 1) / wpb);
         L.threads1 = 64 * wpb;
         L.lds1 = lds1;
+        L.force_tiled = getenv("P2S_FORCE_TILED") ? 1 : 0;   // diagnostics / tests of the tiled kernel
         const int slot = (int)(ch & 1);
         const bool overlap = n_chunks > 1 && !getenv("P2S_NO_OVERLAP");
         hipStream_t side = overlap ? ctx->side_stream : ctx->stream;

@@ -47,6 +47,7 @@ struct P2sTriArgs {
 struct P2sTriLaunch {
     int grid0, threads0, lds0;   // level-0 (streaming) kernel
     int grid1, threads1, lds1;   // search kernel
+    int force_tiled;             // diagnostics: use the LDS-tiled streaming kernel even when C <= 8
 };
 
 struct P2sAssocArgs {

@@ -252,13 +252,43 @@ struct UnitObs {
     }
 };
 
+// One unit's observations held in registers (direct kernel, C <= CT): indices must be compile-time
+// constants, which the fully unrolled camera loops provide.
+template <typename T, int CT>
+struct RegObs {
+    T x[CT], y[CT], w[CT];
+    double lik_thr;
+    __device__ __forceinline__ void raw(int c, double &xo, double &yo, double &wo) const {
+        xo = (double)x[c]; yo = (double)y[c]; wo = (double)w[c];
+    }
+    __device__ __forceinline__ void rawT(int c, T &xo, T &yo, T &wo) const { xo = x[c]; yo = y[c]; wo = w[c]; }
+    __device__ __forceinline__ void masked_xy(int c, double &xo, double &yo) const {
+        const bool low = (double)w[c] < lik_thr;
+        xo = low ? d_nan() : (double)x[c];
+        yo = low ? d_nan() : (double)y[c];
+    }
+};
+
+// Camera loop: CT > 0 -> fully unrolled for up to CT cameras (constant indices, and the scheduler sees
+// every load of the pass at once); CT == 0 -> run-time camera count.
+template <int CT, typename F>
+__device__ __forceinline__ void for_each_cam(int C, F &&f) {
+    if constexpr (CT > 0) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+            if (c < C) f(c);
+    } else {
+#pragma unroll 2
+        for (int c = 0; c < C; ++c) f(c);
+    }
+}
+
 // Level-0 pass over all cameras: classify each camera (NaN / zero likelihood) and accumulate the
 // normal matrix of the valid ones.  Branch-free: an invalid camera enters with weight 0.
-template <typename T>
-__device__ __forceinline__ void classify_and_accumulate(cam_cptr cams, int C, const UnitObs<T> &o, double N[10],
+template <typename T, int CT, typename OBS>
+__device__ __forceinline__ void classify_and_accumulate(cam_cptr cams, int C, const OBS &o, double N[10],
                                                          uint32_t &nanmask, uint32_t &zeromask) {
-#pragma unroll 2
-    for (int c = 0; c < C; ++c) {
+    for_each_cam<CT>(C, [&](int c) {
         T x, y, w;
         o.rawT(c, x, y, w);
         const bool isn = !(w == w) || ((double)w < o.lik_thr);
@@ -267,7 +297,7 @@ __device__ __forceinline__ void classify_and_accumulate(cam_cptr cams, int C, co
         zeromask |= isz ? (1u << c) : 0u;
         const bool ok = !(isn || isz);
         accum_camera<1>(N, cams[c].P, (double)(ok ? x : (T)0), (double)(ok ? y : (T)0), (double)(ok ? w : (T)0));
-    }
+    });
 }
 
 // 1/sqrt(t) for 0 < t < inf to ~1 ulp: v_rsq_f64 seed + two Newton steps.
@@ -312,13 +342,11 @@ __device__ __noinline__ double camera_distance_exact(cam_cptr cam, const double 
 }
 
 // Mean reprojection error over the cameras of `kept` (triangulation.py:472-489).
-template <typename T, bool UNDISTORT>
-__device__ __forceinline__ double mean_error(cam_cptr cams, int C, const UnitObs<T> &o, uint32_t kept,
-                                             const double q[3]) {
+template <typename T, bool UNDISTORT, int CT = 0, typename OBS>
+__device__ __forceinline__ double mean_error(cam_cptr cams, int C, const OBS &o, uint32_t kept, const double q[3]) {
     double sum = 0.0;
     bool irregular = false;
-#pragma unroll 2
-    for (int c = 0; c < C; ++c) {
+    for_each_cam<CT>(C, [&](int c) {
         double x, y, w;
         o.raw(c, x, y, w);
         const bool k = (kept >> c) & 1u;
@@ -326,15 +354,15 @@ __device__ __forceinline__ double mean_error(cam_cptr cams, int C, const UnitObs
         const double d = camera_distance<UNDISTORT>(cams + c, q, x, y, reg);
         irregular = irregular || (k && !reg);
         sum += k ? d : 0.0;
-    }
+    });
     if (__any(irregular)) {                        // rare: some wanted camera is degenerate / NaN
         double sum2 = 0.0;
-        for (int c = 0; c < C; ++c) {
+        for_each_cam<CT>(C, [&](int c) {
             double x, y, w;
             o.raw(c, x, y, w);
             const double d = camera_distance_exact(cams + c, q, x, y);
             sum2 += ((kept >> c) & 1u) ? d : 0.0;
-        }
+        });
         sum = irregular ? sum2 : sum;
     }
     return sum * fast_rcp((double)__popc(kept));   // no camera kept -> NaN, as np.mean([])
@@ -343,14 +371,14 @@ __device__ __forceinline__ double mean_error(cam_cptr cams, int C, const UnitObs
 // L/R-swap candidate (triangulation.py:509-561, quirk Q3): the first M kept cameras carry the
 // mirrored keypoint's (x, y), still weighted by the unit's own likelihoods; the error is the mean
 // over those first M cameras only.
-template <typename T, bool UNDISTORT>
-__device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const UnitObs<T> &o, const UnitObs<T> &osw,
-                                                 uint32_t kept, int M, double qs[3]) {
+template <typename T, bool UNDISTORT, int CT = 0, typename OBS>
+__device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const OBS &o, const OBS &osw, uint32_t kept,
+                                                 int M, double qs[3]) {
     double Nw[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) Nw[i] = 0.0;
     int taken = 0;
-    for (int c = 0; c < C; ++c) {
+    for_each_cam<CT>(C, [&](int c) {
         double x, y, w, xs, ys;
         o.raw(c, x, y, w);
         osw.masked_xy(c, xs, ys);
@@ -358,12 +386,12 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const Uni
         const bool sw = taken < M;
         accum_camera<1>(Nw, cams[c].P, k ? (sw ? xs : x) : 0.0, k ? (sw ? ys : y) : 0.0, k ? w : 0.0);
         taken += k ? 1 : 0;
-    }
+    });
     smallest_eigvec(Nw, qs);
     double sum = 0.0;
     bool irregular = false;
     taken = 0;
-    for (int c = 0; c < C; ++c) {
+    for_each_cam<CT>(C, [&](int c) {
         double xs, ys;
         osw.masked_xy(c, xs, ys);
         const bool k = ((kept >> c) & 1u) && taken < M;
@@ -372,18 +400,18 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const Uni
         irregular = irregular || (k && !reg);
         sum += k ? d : 0.0;
         taken += ((kept >> c) & 1u) ? 1 : 0;
-    }
+    });
     if (__any(irregular)) {
         double sum2 = 0.0;
         taken = 0;
-        for (int c = 0; c < C; ++c) {
+        for_each_cam<CT>(C, [&](int c) {
             double xs, ys;
             osw.masked_xy(c, xs, ys);
             const bool k = ((kept >> c) & 1u) && taken < M;
             const double d = camera_distance_exact(cams + c, qs, xs, ys);
             sum2 += k ? d : 0.0;
             taken += ((kept >> c) & 1u) ? 1 : 0;
-        }
+        });
         sum = irregular ? sum2 : sum;
     }
     return sum * fast_rcp((double)M);
@@ -407,6 +435,8 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int64_t tile0 = a.block0 + (int64_t)blockIdx.x * FB;     // first block of this tile
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;   // diagnostics (debug_mode 4)
+    if (a.debug_mode == 4) st0 = __builtin_amdgcn_s_memtime();
     const int nb = (int)min((int64_t)FB, a.block0 + a.n_blocks - tile0);
     const int n_units = nb * K;
 
@@ -423,6 +453,7 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
         for (int i = n_vec * VEC + tid; i < n_elems; i += blockDim.x) tile[i] = src[i];
     }
     __syncthreads();
+    if (a.debug_mode == 4) st1 = __builtin_amdgcn_s_memtime();
 
     // ---- prepare: undistort in place (the mirrored keypoint of another lane reads it too) ----
     if (UNDISTORT) {
@@ -468,7 +499,8 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
 #pragma unroll
         for (int i = 0; i < 10; ++i) N[i] = 0.0;
         uint32_t nanmask = 0, zeromask = 0;
-        classify_and_accumulate<T>(cams, C, obs, N, nanmask, zeromask);
+        classify_and_accumulate<T, 0>(cams, C, obs, N, nanmask, zeromask);
+        if (a.debug_mode == 4) { __builtin_amdgcn_sched_barrier(0); st2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         const uint32_t dmask = nanmask | zeromask;                 // cameras already out (NaN or zero likelihood)
         const uint32_t valid = allmask & ~dmask;
         const int V = __popc(dmask);
@@ -482,8 +514,10 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
         {
             double q[3];
             smallest_eigvec(N, q);
+            if (a.debug_mode == 4) { __builtin_amdgcn_sched_barrier(0); st3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
             if (nvalid < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }   // common.py:347: fewer than 4 rows
-            const double e = mean_error<T, UNDISTORT>(cams, C, obs, valid, q);
+            const double e = mean_error<T, UNDISTORT, 0>(cams, C, obs, valid, q);
+            if (a.debug_mode == 4) { __builtin_amdgcn_sched_barrier(0); st4 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
             if (Lmax >= 0) {
                 err_min = e; Qb[0] = q[0]; Qb[1] = q[1]; Qb[2] = q[2];
                 n_excl = V; mask = nanmask;
@@ -493,7 +527,7 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
             const bool want = (Lmax >= 0) && (err_min > thr) && (nvalid > 2);
             if (__any(want)) {
                 double qs[3];
-                const double es = swap_candidate<T, UNDISTORT>(cams, C, obs, obs_sw, valid, nvalid, qs);
+                const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, obs, obs_sw, valid, nvalid, qs);
                 if (want && es < err_min) { err_min = es; Qb[0] = qs[0]; Qb[1] = qs[1]; Qb[2] = qs[2]; }
             }
         }
@@ -510,6 +544,11 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
             a.err[gu] = fail ? __builtin_nanf("") : (float)err_min;
             a.n_excl[gu] = (uint8_t)n_excl;
             a.mask[gu] = mask;
+            if (a.debug_mode == 4 && tid == 0) {   // diagnostics: phase stamps of wave 0 instead of unit 0/1 results
+                st5 = __builtin_amdgcn_s_memtime();
+                Qo[0] = (double)(st1 - st0); Qo[1] = (double)(st2 - st1); Qo[2] = (double)(st3 - st2);
+                Qo[3] = (double)(st4 - st3); Qo[4] = (double)(st5 - st4); Qo[5] = (double)(st5 - st0);
+            }
         }
 
         // ---- work list: one atomic per wave, records written by their lanes --------------------
@@ -536,6 +575,151 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
                         rs[c * 3 + 0] = obs_sw.p[c * strideC + 0];
                         rs[c * 3 + 1] = obs_sw.p[c * strideC + 1];
                         rs[c * 3 + 2] = obs_sw.p[c * strideC + 2];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1, direct form (C <= CT): one lane per unit, no LDS and no barrier.  Lane u loads its C
+// observations straight from HBM into registers -- consecutive lanes are consecutive keypoints, so
+// every load instruction of a wave reads runs of 12-byte triplets that are contiguous per (frame,
+// person) block, and over the C loads the wave consumes every byte of the blocks it covers exactly
+// once.  Without a staged tile the waves of a CU are independent: the ~2 us HBM latency of one wave
+// hides under the arithmetic of the others instead of stalling a whole workgroup at a barrier.
+template <typename T, bool UNDISTORT, bool LRSWAP, int CT>
+__global__ void __launch_bounds__(256, 4) p2s_tri_level0_direct_kernel(const P2sTriArgs a) {
+    const int C = a.C, K = a.K;
+    cam_cptr cams = (cam_cptr)a.cams;
+    const int lane = threadIdx.x & 63;
+    const int64_t n_units = a.n_blocks * K;
+    const int64_t lu = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // unit within the chunk
+    if (lu - lane >= n_units) return;                                      // whole wave past the chunk
+    const bool active = lu < n_units;
+    const int64_t u = active ? lu : 0;
+    const int64_t b = u / K;
+    const int k = (int)(u - b * K);
+    const int64_t gb = a.block0 + b;
+    const T *base = reinterpret_cast<const T *>(a.xyl) + (a.debug_mode == 2 ? 0 : gb * (int64_t)C * K * 3);
+
+    RegObs<T, CT> obs, obs_sw;
+    obs.lik_thr = a.lik_thr;
+    obs_sw.lik_thr = a.lik_thr;
+    const int ks = LRSWAP ? a.swap_idx[k] : k;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (c < C) {
+            const T *p = base + ((int64_t)c * K + k) * 3;
+            obs.x[c] = __builtin_nontemporal_load(p);
+            obs.y[c] = __builtin_nontemporal_load(p + 1);
+            obs.w[c] = __builtin_nontemporal_load(p + 2);
+            if (LRSWAP) {
+                const T *ps = base + ((int64_t)c * K + ks) * 3;
+                obs_sw.x[c] = ps[0]; obs_sw.y[c] = ps[1]; obs_sw.w[c] = ps[2];
+            }
+        } else {
+            obs.x[c] = obs.y[c] = obs.w[c] = (T)0;
+            obs_sw.x[c] = obs_sw.y[c] = obs_sw.w[c] = (T)0;
+        }
+    }
+    if (UNDISTORT) {          // triangulation.py:808-813 (float32 in / out); the mirrored keypoint too
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            if (c < C) {
+                double x = (double)obs.x[c], y = (double)obs.y[c];
+                undistort_point(cams + c, x, y);
+                obs.x[c] = (T)x; obs.y[c] = (T)y;
+                if (LRSWAP) {
+                    double xs = (double)obs_sw.x[c], ys = (double)obs_sw.y[c];
+                    undistort_point(cams + c, xs, ys);
+                    obs_sw.x[c] = (T)xs; obs_sw.y[c] = (T)ys;
+                }
+            }
+        }
+    }
+
+    const double thr = a.thr;
+    const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+    const int64_t gu = gb * K + k;
+
+    if (a.debug_mode == 1) {   // diagnostics: memory skeleton only
+        if (active) {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) s += (double)obs.x[c] + (double)obs.y[c] + (double)obs.w[c];
+            a.Q[gu * 3] = s; a.Q[gu * 3 + 1] = s; a.Q[gu * 3 + 2] = s;
+            a.err[gu] = (float)s; a.n_excl[gu] = 0; a.mask[gu] = 0;
+        }
+        return;
+    }
+
+    double N[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) N[i] = 0.0;
+    uint32_t nanmask = 0, zeromask = 0;
+    classify_and_accumulate<T, CT>(cams, C, obs, N, nanmask, zeromask);
+    const uint32_t dmask = nanmask | zeromask;                 // cameras already out (NaN or zero likelihood)
+    const uint32_t valid = allmask & ~dmask;
+    const int V = __popc(dmask);
+    const int nvalid = C - V;
+    const int Lmax = active ? C - a.min_cams - V : -1;         // last level that runs (triangulation.py:408, 437-441)
+
+    double err_min = kInf;
+    double Qb[3] = {d_nan(), d_nan(), d_nan()};
+    int n_excl = C;                                            // :595-596 when no level completes
+    uint32_t mask = allmask;
+    {
+        double q[3];
+        smallest_eigvec(N, q);
+        if (nvalid < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }   // common.py:347: fewer than 4 rows
+        const double e = mean_error<T, UNDISTORT, CT>(cams, C, obs, valid, q);
+        if (Lmax >= 0) {
+            err_min = e; Qb[0] = q[0]; Qb[1] = q[1]; Qb[2] = q[2];
+            n_excl = V; mask = nanmask;
+        }
+    }
+    if (LRSWAP) {                                              // :509-579 at level 0: M = nvalid
+        const bool want = (Lmax >= 0) && (err_min > thr) && (nvalid > 2);
+        if (__any(want)) {
+            double qs[3];
+            const double es = swap_candidate<T, UNDISTORT, CT>(cams, C, obs, obs_sw, valid, nvalid, qs);
+            if (want && es < err_min) { err_min = es; Qb[0] = qs[0]; Qb[1] = qs[1]; Qb[2] = qs[2]; }
+        }
+    }
+    const bool need = (Lmax >= 1) && (err_min > thr);          // goes on to level 1 (kernel 2)
+
+    if (active) {                                              // triangulation.py:588-604
+        const bool fail = !(err_min <= thr);
+        double *Qo = a.Q + gu * 3;
+        Qo[0] = fail ? d_nan() : Qb[0];
+        Qo[1] = fail ? d_nan() : Qb[1];
+        Qo[2] = fail ? d_nan() : Qb[2];
+        a.err[gu] = fail ? __builtin_nanf("") : (float)err_min;
+        a.n_excl[gu] = (uint8_t)n_excl;
+        a.mask[gu] = mask;
+    }
+
+    const unsigned long long hard = __ballot(need);
+    if (hard != 0ull) {
+        uint32_t base_rec = 0;
+        const uint32_t shard = blockIdx.x % P2S_WL_SHARDS;
+        if (lane == 0) base_rec = atomicAdd(a.wl_count + shard, (uint32_t)__popcll(hard));
+        base_rec = __shfl(base_rec, 0, 64);
+        if (need) {
+            const uint32_t slot = base_rec + (uint32_t)__popcll(hard & ((1ull << lane) - 1ull));
+            unsigned char *rec = a.wl_rec + ((size_t)shard * a.wl_capacity + slot) * a.rec_bytes;
+            reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)lu;       // unit id within the chunk
+            reinterpret_cast<uint32_t *>(rec)[1] = 0u;
+            T *ro = reinterpret_cast<T *>(rec + 8);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (c < C) {
+                    ro[c * 3 + 0] = obs.x[c]; ro[c * 3 + 1] = obs.y[c]; ro[c * 3 + 2] = obs.w[c];
+                    if (LRSWAP) {
+                        T *rs = ro + C * 3;
+                        rs[c * 3 + 0] = obs_sw.x[c]; rs[c * 3 + 1] = obs_sw.y[c]; rs[c * 3 + 2] = obs_sw.w[c];
                     }
                 }
             }
@@ -601,7 +785,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
 #pragma unroll
         for (int i = 0; i < 10; ++i) N[i] = 0.0;
         uint32_t nanmask = 0, zeromask = 0;
-        classify_and_accumulate<T>(cams, C, obs, N, nanmask, zeromask);
+        classify_and_accumulate<T, 0>(cams, C, obs, N, nanmask, zeromask);
         const int V = __popc(nanmask | zeromask);
         const int Lmax = active ? C - a.min_cams - V : -1;
 
@@ -689,11 +873,11 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                     double q[3];
                     smallest_eigvec(Ns, q);
                     if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
-                    const double e = mean_error<T, UNDISTORT>(cams, C, oobs, kept, q);
+                    const double e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
                     if (go && (e < be || brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
                     if (LRSWAP && M > 2) {
                         double qs[3];
-                        const double es = swap_candidate<T, UNDISTORT>(cams, C, oobs, oobs_sw, kept, M, qs);
+                        const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
                         if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
                     }
                 }
@@ -733,7 +917,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 if (is_owner_now) {
                     err_min = r_err; Qb[0] = r_q0; Qb[1] = r_q1; Qb[2] = r_q2;
                     mask = r_mask; n_excl = r_nexcl;
-                    cont = (err_min > thr) && (level + 1 <= Lmax);
+                    cont = (err_min > thr) && (level + 1 <= Lmax) && (a.debug_mode != 3);
                 }
             }
             pend_level = __ballot(cont);
@@ -760,16 +944,27 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
 // Kernel 1 goes to the main stream, kernel 2 to the side stream behind an event, so that the search
 // of one chunk runs beside the streaming pass of the next.
 template <typename T, bool U, bool L>
-static hipError_t launch_both(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
-                              hipEvent_t k1_done) {
+static hipError_t launch_level0(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s) {
+    if (a.C <= 8 && !g.force_tiled) {        // register-resident observations, no LDS
+        const int64_t n_units = a.n_blocks * a.K;
+        const unsigned grid = (unsigned)((n_units + 255) / 256);
+        hipLaunchKernelGGL((p2s_tri_level0_direct_kernel<T, U, L, 8>), dim3(grid), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_level0_kernel<T, U, L>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds0);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((p2s_tri_level0_kernel<T, U, L>), dim3(g.grid0), dim3(g.threads0), g.lds0, s, a);
+    return hipGetLastError();
+}
+
+template <typename T, bool U, bool L>
+static hipError_t launch_both(const P2sTriArgs &a, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
+                              hipEvent_t k1_done) {
+    hipError_t e = launch_level0<T, U, L>(a, g, s);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_search_kernel<T, U, L>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, g.lds1);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((p2s_tri_level0_kernel<T, U, L>), dim3(g.grid0), dim3(g.threads0), g.lds0, s, a);
-    e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (a.debug_mode == 1) return hipSuccess;
     if (side != s) {
