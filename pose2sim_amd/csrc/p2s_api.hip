@@ -318,9 +318,9 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     // search kernel geometry: LDS = [P][binom][waves x 64 records]
     const int lds_binom_off = (C * 12 * 8 + 15) / 16 * 16;
     const int lds_rec_off = (lds_binom_off + 33 * 33 * 4 + 15) / 16 * 16;
-    const int64_t fit = (40 * 1024) / (64 * (int64_t)rec_bytes);
+    const int64_t fit = (40 * 1024) / (64 * (int64_t)(rec_bytes + 96));
     const int wpb = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;   // waves per search workgroup
-    const int lds1 = lds_rec_off + wpb * 64 * rec_bytes;
+    const int lds1 = lds_rec_off + wpb * 64 * (rec_bytes + 96);   // per wave: 64 records + 64 owner states
     if (lds1 > 160 * 1024) return fail(P2S_ERR_INVALID_ARG, "search records of C=%d do not fit in LDS", C);
 
     P2sTriArgs a{};

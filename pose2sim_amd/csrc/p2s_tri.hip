@@ -742,7 +742,9 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int waves_per_block = blockDim.x >> 6;
-    unsigned char *recs = smem + a.lds_rec_off + (size_t)wave * 64 * a.rec_bytes;
+    // per wave: 64 records, then 64 owner states {N[10] f64, nanmask u32, zeromask u32, pad} of 96 bytes
+    unsigned char *recs = smem + a.lds_rec_off + (size_t)wave * 64 * (a.rec_bytes + 96);
+    unsigned char *states = recs + (size_t)64 * a.rec_bytes;
 
     for (int i = tid; i < C * 12; i += blockDim.x) sP[i] = a.cams[i / 12].P[i % 12];
     for (int i = tid; i < 33 * 33; i += blockDim.x) sBinom[i] = a.binom[i];
@@ -788,6 +790,16 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         classify_and_accumulate<T, 0>(cams, C, obs, N, nanmask, zeromask);
         const int V = __popc(nanmask | zeromask);
         const int Lmax = active ? C - a.min_cams - V : -1;
+        {   // publish the owner state: the lanes of the group that works on this unit read it from LDS
+            double *sN = reinterpret_cast<double *>(states + (size_t)lane * 96);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) sN[i] = N[i];
+            reinterpret_cast<uint32_t *>(sN + 10)[0] = nanmask;
+            reinterpret_cast<uint32_t *>(sN + 10)[1] = zeromask;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         double err_min = kInf;
         double Qb[3] = {d_nan(), d_nan(), d_nan()};
@@ -822,12 +834,11 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 const unsigned long long batch = before & ~pending;   // owners served in this pass
                 const int owner = nth_set_bit(batch, grp);            // record this group works on (lane id) or -1
 
-                // gather the owner's state
+                // the owner's state
                 const int src = owner < 0 ? lane : owner;
-                const uint32_t o_nan = __shfl(nanmask, src, 64), o_zero = __shfl(zeromask, src, 64);
-                double No[10];
-#pragma unroll
-                for (int i = 0; i < 10; ++i) No[i] = shfl_d(N[i], src);
+                const double *oN = reinterpret_cast<const double *>(states + (size_t)src * 96);
+                const uint32_t o_nan = reinterpret_cast<const uint32_t *>(oN + 10)[0];
+                const uint32_t o_zero = reinterpret_cast<const uint32_t *>(oN + 10)[1];
                 const uint32_t o_d = o_nan | o_zero, o_valid = allmask & ~o_d;
                 const int oV = __popc(o_d);
                 const unsigned char *orec = recs + (size_t)src * a.rec_bytes;
@@ -862,7 +873,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                     const int nkept = __popc(kept);
                     double Ns[10];
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) Ns[i] = No[i];
+                    for (int i = 0; i < 10; ++i) Ns[i] = oN[i];
                     for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
                         const int c = rr ? __builtin_ctz(rr) : 0;
                         double x, y, w;
