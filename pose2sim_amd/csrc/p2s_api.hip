@@ -293,7 +293,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     Geometry g = choose_geometry(C, n_kpts, dtype);
     if (g.FB == 0) return fail(P2S_ERR_INVALID_ARG, "one block of C=%d x K=%d does not fit in LDS", C, n_kpts);
     const int elem = dtype == P2S_F32 ? 4 : 8;
-    const int rec_bytes = 8 + 3 * C * elem * (params->handle_lr_swap ? 2 : 1);
+    const int rec_bytes = P2S_REC_HDR + (3 * C * elem * (params->handle_lr_swap ? 2 : 1) + 15) / 16 * 16;
 
     // chunks of whole tiles, at most kChunkUnits units each
     int64_t chunk_blocks = std::max<int64_t>(g.FB, (kChunkUnits / n_kpts) / g.FB * g.FB);

@@ -21,6 +21,7 @@ struct P2sCam {
 // The work list is cut into shards (workgroup b appends to shard b % P2S_WL_SHARDS) so that the
 // append counters do not serialise: one returning atomic per wave on ONE word caps near 90 per us.
 #define P2S_WL_SHARDS 128
+#define P2S_REC_HDR 16           // record header: u32 unit in chunk + padding to 16 bytes (records are 16-byte multiples)
 
 struct P2sTriArgs {
     const void *xyl;             // whole tensor [n_blocks_total][C][K][3]
@@ -32,7 +33,7 @@ struct P2sTriArgs {
     const P2sCam *cams;
     const uint32_t *binom;       // [33][33] binomial coefficients
     uint32_t *wl_count;          // work list of this chunk: P2S_WL_SHARDS record counts, then P2S_WL_SHARDS job tickets (zeroed before kernel 1)
-    unsigned char *wl_rec;       // records: {u32 unit id in chunk, u32 pad, T obs[C][3] (, T obs_swapped[C][3])}
+    unsigned char *wl_rec;       // records: {u32 unit id in chunk, pad to 16 B, T obs[C][3] (, T obs_swapped[C][3]), pad to 16 B}
     int64_t block0;              // first (frame, person) block of this chunk
     int64_t n_blocks;            // blocks in this chunk
     uint32_t wl_capacity;        // records per shard

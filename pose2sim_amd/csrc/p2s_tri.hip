@@ -333,10 +333,11 @@ __device__ __forceinline__ double camera_distance(cam_cptr cam, const double q[3
 }
 
 // The literal formula with the reference's NaN rules (all-NaN difference -> inf, nansum).
-__device__ __noinline__ double camera_distance_exact(cam_cptr cam, const double q[3], double x, double y) {
-    const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
-    const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], fma(cam->P[6], q[2], cam->P[7])));
-    const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], fma(cam->P[10], q[2], cam->P[11])));
+// (q by value: a pointer argument of a non-inlined function would force q into scratch memory)
+__device__ __noinline__ double camera_distance_exact(cam_cptr cam, double q0, double q1, double q2, double x, double y) {
+    const double a = fma(cam->P[0], q0, fma(cam->P[1], q1, fma(cam->P[2], q2, cam->P[3])));
+    const double b = fma(cam->P[4], q0, fma(cam->P[5], q1, fma(cam->P[6], q2, cam->P[7])));
+    const double z = fma(cam->P[8], q0, fma(cam->P[9], q1, fma(cam->P[10], q2, cam->P[11])));
     const double rz = fast_rcp(z);
     return pair_distance(a * rz - x, b * rz - y);
 }
@@ -360,7 +361,7 @@ __device__ __forceinline__ double mean_error(cam_cptr cams, int C, const OBS &o,
         for_each_cam<CT>(C, [&](int c) {
             double x, y, w;
             o.raw(c, x, y, w);
-            const double d = camera_distance_exact(cams + c, q, x, y);
+            const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], x, y);
             sum2 += ((kept >> c) & 1u) ? d : 0.0;
         });
         sum = irregular ? sum2 : sum;
@@ -408,7 +409,7 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const OBS
             double xs, ys;
             osw.masked_xy(c, xs, ys);
             const bool k = ((kept >> c) & 1u) && taken < M;
-            const double d = camera_distance_exact(cams + c, qs, xs, ys);
+            const double d = camera_distance_exact(cams + c, qs[0], qs[1], qs[2], xs, ys);
             sum2 += k ? d : 0.0;
             taken += ((kept >> c) & 1u) ? 1 : 0;
         });
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
                 unsigned char *rec = a.wl_rec + ((size_t)shard * a.wl_capacity + slot) * a.rec_bytes;
                 reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)(tile0 * K + u - a.block0 * K);   // unit id within the chunk
                 reinterpret_cast<uint32_t *>(rec)[1] = 0u;
-                T *ro = reinterpret_cast<T *>(rec + 8);
+                T *ro = reinterpret_cast<T *>(rec + P2S_REC_HDR);
                 for (int c = 0; c < C; ++c) {
                     ro[c * 3 + 0] = obs.p[c * strideC + 0];
                     ro[c * 3 + 1] = obs.p[c * strideC + 1];
@@ -690,15 +691,59 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_direct_kernel(const P2s
     }
     const bool need = (Lmax >= 1) && (err_min > thr);          // goes on to level 1 (kernel 2)
 
-    if (active) {                                              // triangulation.py:588-604
+    {   // triangulation.py:588-604.  The three doubles of a unit sit 24 bytes apart: transposing the
+        // wave's 64 x 3 block through LDS turns three 8-byte-strided stores into three stores of 512
+        // contiguous bytes (sub-line stores inflated the HBM write traffic by ~1.5x).
+        __shared__ __align__(16) double sQ[4][192];
+        const int wv = threadIdx.x >> 6;
         const bool fail = !(err_min <= thr);
-        double *Qo = a.Q + gu * 3;
-        Qo[0] = fail ? d_nan() : Qb[0];
-        Qo[1] = fail ? d_nan() : Qb[1];
-        Qo[2] = fail ? d_nan() : Qb[2];
-        a.err[gu] = fail ? __builtin_nanf("") : (float)err_min;
-        a.n_excl[gu] = (uint8_t)n_excl;
-        a.mask[gu] = mask;
+        sQ[wv][lane * 3 + 0] = fail ? d_nan() : Qb[0];
+        sQ[wv][lane * 3 + 1] = fail ? d_nan() : Qb[1];
+        sQ[wv][lane * 3 + 2] = fail ? d_nan() : Qb[2];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t wave_u0 = a.block0 * K + (lu - lane);        // first unit of this wave (global)
+        const int64_t n_left = n_units - (lu - lane);              // units this wave owns
+        double *Qw = a.Q + wave_u0 * 3;
+        if (n_left >= 64 && ((reinterpret_cast<uintptr_t>(Qw) & 15) == 0)) {
+            // full wave: 1536 contiguous bytes as 16-byte stores (64 lanes, then the first 32)
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d *src = reinterpret_cast<const v2d *>(&sQ[wv][0]);
+            v2d *dst = reinterpret_cast<v2d *>(Qw);
+            dst[lane] = src[lane];
+            if (lane < 32) dst[64 + lane] = src[64 + lane];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int idx = r * 64 + lane;
+                if (idx < 3 * n_left) Qw[idx] = sQ[wv][idx];
+            }
+        }
+        // the 4-byte and 1-byte outputs the same way: 16 bytes per storing lane
+        __shared__ __align__(16) uint32_t sE[4][64], sM[4][64];
+        __shared__ __align__(16) uint8_t sX[4][64];
+        sE[wv][lane] = __float_as_uint(fail ? __builtin_nanf("") : (float)err_min);
+        sM[wv][lane] = mask;
+        sX[wv][lane] = (uint8_t)n_excl;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float *Ew = a.err + wave_u0;
+        uint32_t *Mw = a.mask + wave_u0;
+        uint8_t *Xw = a.n_excl + wave_u0;
+        const bool al16 = ((reinterpret_cast<uintptr_t>(Ew) | reinterpret_cast<uintptr_t>(Mw) |
+                            reinterpret_cast<uintptr_t>(Xw)) & 15) == 0;
+        if (n_left >= 64 && al16) {
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            if (lane < 16) reinterpret_cast<v4u *>(Ew)[lane] = reinterpret_cast<const v4u *>(&sE[wv][0])[lane];
+            else if (lane < 32) reinterpret_cast<v4u *>(Mw)[lane - 16] = reinterpret_cast<const v4u *>(&sM[wv][0])[lane - 16];
+            else if (lane < 36) reinterpret_cast<v4u *>(Xw)[lane - 32] = reinterpret_cast<const v4u *>(&sX[wv][0])[lane - 32];
+        } else if (active) {
+            a.err[gu] = fail ? __builtin_nanf("") : (float)err_min;
+            a.n_excl[gu] = (uint8_t)n_excl;
+            a.mask[gu] = mask;
+        }
     }
 
     const unsigned long long hard = __ballot(need);
@@ -710,17 +755,30 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_direct_kernel(const P2s
         if (need) {
             const uint32_t slot = base_rec + (uint32_t)__popcll(hard & ((1ull << lane) - 1ull));
             unsigned char *rec = a.wl_rec + ((size_t)shard * a.wl_capacity + slot) * a.rec_bytes;
-            reinterpret_cast<uint32_t *>(rec)[0] = (uint32_t)lu;       // unit id within the chunk
-            reinterpret_cast<uint32_t *>(rec)[1] = 0u;
-            T *ro = reinterpret_cast<T *>(rec + 8);
+            // 16-byte stores: the record is a 16-byte header + the observations, padded to 16 bytes
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            v4u *r16 = reinterpret_cast<v4u *>(rec);
+            r16[0] = v4u{(uint32_t)lu, 0u, 0u, 0u};               // unit id within the chunk
+            constexpr int PER = 16 / sizeof(T);                    // values per 16-byte store
+            T flat[2 * CT * 3 + PER];
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                if (c < C) {
-                    ro[c * 3 + 0] = obs.x[c]; ro[c * 3 + 1] = obs.y[c]; ro[c * 3 + 2] = obs.w[c];
-                    if (LRSWAP) {
-                        T *rs = ro + C * 3;
-                        rs[c * 3 + 0] = obs_sw.x[c]; rs[c * 3 + 1] = obs_sw.y[c]; rs[c * 3 + 2] = obs_sw.w[c];
-                    }
+                flat[c * 3 + 0] = obs.x[c]; flat[c * 3 + 1] = obs.y[c]; flat[c * 3 + 2] = obs.w[c];
+            }
+            // C < CT: the swapped block starts right after the C real cameras
+#pragma unroll
+            for (int i = 0; i < (CT * 3 + PER - 1) / PER; ++i) {
+                if (i * PER < C * 3) {
+                    v4u v;
+                    __builtin_memcpy(&v, &flat[i * PER], 16);
+                    r16[1 + i] = v;
+                }
+            }
+            if (LRSWAP) {
+                T *rs = reinterpret_cast<T *>(rec + P2S_REC_HDR) + C * 3;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (c < C) { rs[c * 3 + 0] = obs_sw.x[c]; rs[c * 3 + 1] = obs_sw.y[c]; rs[c * 3 + 2] = obs_sw.w[c]; }
                 }
             }
         }
@@ -780,7 +838,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         const bool active = lane < n;
         const unsigned char *myrec = recs + (size_t)(active ? lane : 0) * a.rec_bytes;
         const uint32_t u = *reinterpret_cast<const uint32_t *>(myrec);          // unit id within the chunk
-        UnitObs<T> obs{reinterpret_cast<const T *>(myrec + 8), 3, a.lik_thr};
+        UnitObs<T> obs{reinterpret_cast<const T *>(myrec + P2S_REC_HDR), 3, a.lik_thr};
 
         // level-0 state again (cheaper than carrying 80 bytes per unit through HBM)
         double N[10];
@@ -842,7 +900,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 const uint32_t o_d = o_nan | o_zero, o_valid = allmask & ~o_d;
                 const int oV = __popc(o_d);
                 const unsigned char *orec = recs + (size_t)src * a.rec_bytes;
-                UnitObs<T> oobs{reinterpret_cast<const T *>(orec + 8), 3, a.lik_thr};
+                UnitObs<T> oobs{reinterpret_cast<const T *>(orec + P2S_REC_HDR), 3, a.lik_thr};
                 UnitObs<T> oobs_sw = oobs;
                 if (LRSWAP) oobs_sw.p = oobs.p + C * 3;
                 const int M = C - oV - level;                       // cameras left when `level` valid ones go (:437, 513)
