@@ -189,10 +189,18 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    # rehearsal on a one-GPU box: P2S_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device); the driver's multi-GPU runs never set it
+    rehearsal = os.environ.get('P2S_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -225,17 +233,53 @@ def main():
     off_m = off_e + n_units * 4
     off_n = off_m + n_units * 4
     nbytes = (off_n + n_units + 15) // 16 * 16
-    d_out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # two result buffers: the all-gather of step i runs on RCCL's stream while step i+1 computes
+    d_outs = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    d_alls = [torch.empty(nbytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else []
+    d_out = d_outs[0]
     base = d_out.data_ptr()
-    d_all = torch.empty(nbytes * world, dtype=torch.uint8, device=dev) if world > 1 else None
+    pending = [None, None]
+    counter = [0]
 
     def step():
-        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, base, base + off_e, base + off_n, base + off_m)
+        i = counter[0] % len(d_outs)
+        counter[0] += 1
+        if world > 1 and pending[i] is not None:
+            pending[i].wait()                      # buffer i is free again (its all-gather has finished)
+        b = d_outs[i].data_ptr()
+        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, b, b + off_e, b + off_n, b + off_m)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            pending[i] = dist.all_gather_into_tensor(d_alls[i], d_outs[i], async_op=True)
+
+    def drain():
+        for w in pending:
+            if w is not None:
+                w.wait()
+        pending[0] = pending[1] = None
 
     def kernel_only():
         eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, base, base + off_e, base + off_n, base + off_m)
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain()                                        # every all-gather of the K steps is inside the timed region
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -293,7 +337,7 @@ def main():
                        'params': {'thr_px': cfg['thr'], 'lik_thr': cfg['lik'], 'min_cams': cfg['min_cams'],
                                   'undistort': cfg['undistort'], 'lr_swap': cfg['lr_swap']},
                        'accepted_fraction': ok_frac, 'tile': eng.tri_geometry(K),
-                       'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step' if world > 1 else '')},
+                       'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
