@@ -23,6 +23,7 @@
 
 #include "p2s.h"
 #include "p2s_internal.h"
+#include "p2s_math.h"
 
 namespace {
 
@@ -42,17 +43,78 @@ __device__ __forceinline__ void lds_fence() {
 __device__ __forceinline__ void rr_pair(int n, int s, int k, int &p, int &q) {
     const int m = n - 1;
     if (k == 0) { p = m; q = s; return; }
-    p = (s + k) % m;
-    q = (s - k + m) % m;
+    p = s + k; p -= (p >= m) ? m : 0;          // (s + k) mod m, operands < m
+    q = s - k; q += (q < 0) ? m : 0;           // (s - k) mod m
 }
 
 // One-sided Jacobi SVD of the n x n matrix stored column-major in A (column j at A + j*n): on return
-// the columns of A are sigma_j u_j and V (column-major) holds the right singular vectors.
-__device__ void jacobi_svd(double *A, double *V, int n, int lane) {
+// the columns of A are sigma_j u_j and V (column-major) holds the right singular vectors (V must hold
+// an orthogonal matrix on entry: the identity, or the previous iteration's V for a warm start, in
+// which case A must already be (input matrix) . V).
+// RPL = rows per lane (compile time): the RPL column elements a lane owns are read with one batch of
+// LDS loads and held in registers, so a round-robin step costs two LDS round trips instead of 4*RPL.
+template <int RPL, int L>
+__device__ void jacobi_svd_t(double *A, double *V, int n, int lane) {
     const int npairs = n >> 1;
-    int L = 1;
-    while ((L << 1) * npairs <= 64) L <<= 1;            // lanes per column pair (power of two)
-    const int rpl = (n + L - 1) / L;                    // rows per lane
+    const int rpl = (n + L - 1) / L;                    // rows per lane (<= RPL)
+    const int k = lane / L, sub = lane - k * L;
+    const bool on = k < npairs;
+    const int r0 = sub * rpl, cnt = on ? max(0, min(n, r0 + rpl) - r0) : 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int s = 0; s < n - 1; ++s) {
+            int p = 0, q = 1;
+            if (on) rr_pair(n, s, k, p, q);
+            double *ap = A + p * n + r0, *aq = A + q * n + r0, *vp = V + p * n + r0, *vq = V + q * n + r0;
+            double x[RPL], y[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const bool in = i < cnt;
+                x[i] = in ? ap[i] : 0.0;
+                y[i] = in ? aq[i] : 0.0;
+            }
+            double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) { al = fma(x[i], x[i], al); be = fma(y[i], y[i], be); ga = fma(x[i], y[i], ga); }
+#pragma unroll
+            for (int off = L >> 1; off > 0; off >>= 1) {
+                al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
+            }
+            // rotate when |ga| > 1e-15 sqrt(al be)  (compared squared: no square root on the test)
+            const bool rot = on && (ga * ga > 1e-30 * (al * be)) && (ga != 0.0);
+            if (__any(rot)) {
+                // Rutishauser's stable formulas; reciprocal / square roots by Newton from the hardware
+                // seeds: the rotation only has to be orthogonal to working precision
+                const double zeta = (be - al) * p2s_rcp(2.0 * ga);
+                const double tt = p2s_rcp(fabs(zeta) + p2s_sqrt(fma(zeta, zeta, 1.0)));
+                const double t = (zeta >= 0.0) ? tt : -tt;
+                const double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
+                double vx[RPL], vy[RPL];
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const bool in = rot && i < cnt;
+                    vx[i] = in ? vp[i] : 0.0;
+                    vy[i] = in ? vq[i] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    if (rot && i < cnt) {
+                        ap[i] = c * x[i] - sn * y[i]; aq[i] = sn * x[i] + c * y[i];
+                        vp[i] = c * vx[i] - sn * vy[i]; vq[i] = sn * vx[i] + c * vy[i];
+                    }
+                }
+            }
+            rotated = rotated || rot;
+            lds_fence();
+        }
+        if (!__any(rotated)) break;
+    }
+}
+
+// Streaming form for wide columns (n > 32: more than 8 rows per lane would not fit the register file).
+__device__ void jacobi_svd_wide(double *A, double *V, int n, int lane, int L) {
+    const int npairs = n >> 1;
+    const int rpl = (n + L - 1) / L;
     const int k = lane / L, sub = lane - k * L;
     const bool on = k < npairs;
     const int r0 = sub * rpl, r1 = min(n, r0 + rpl);
@@ -64,6 +126,7 @@ __device__ void jacobi_svd(double *A, double *V, int n, int lane) {
             double *ap = A + p * n, *aq = A + q * n, *vp = V + p * n, *vq = V + q * n;
             double al = 0.0, be = 0.0, ga = 0.0;
             if (on) {
+#pragma unroll 4
                 for (int r = r0; r < r1; ++r) {
                     const double x = ap[r], y = aq[r];
                     al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga);
@@ -77,6 +140,7 @@ __device__ void jacobi_svd(double *A, double *V, int n, int lane) {
                 const double zeta = (be - al) / (2.0 * ga);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll 4
                 for (int r = r0; r < r1; ++r) {
                     const double x = ap[r], y = aq[r];
                     ap[r] = c * x - sn * y; aq[r] = sn * x + c * y;
@@ -91,9 +155,24 @@ __device__ void jacobi_svd(double *A, double *V, int n, int lane) {
     }
 }
 
+__device__ void jacobi_svd(double *A, double *V, int n, int lane) {
+    const int npairs = n >> 1;
+    int L = 1;
+    while ((L << 1) * npairs <= 64) L <<= 1;            // lanes per column pair (power of two)
+    const int rpl = (n + L - 1) / L;
+    // (L, rows per lane) for even n: n <= 4 -> 32, n <= 8 -> 16, n <= 16 -> 8, n <= 32 -> 4, else 2
+    if (L == 32) jacobi_svd_t<1, 32>(A, V, n, lane);
+    else if (L == 16) jacobi_svd_t<1, 16>(A, V, n, lane);
+    else if (L == 8) jacobi_svd_t<2, 8>(A, V, n, lane);
+    else if (L == 4) jacobi_svd_t<8, 4>(A, V, n, lane);
+    else jacobi_svd_wide(A, V, n, lane, L);
+}
+
 }  // namespace
 
-// LDS (doubles): A[n*n] V[n*n] Y[n*n] X[n*n] W[n*n] wts[n] ; ints: view[n], first[n] (person -> kpts row)
+// LDS (doubles): A[n*n] V[n*n] Y[n*n] X[n*n] wts[n] ; ints: view[n].  The constant matrix W of matchSVT
+// (read twice per element per iteration) lives in the frame's slab of the output buffer in HBM/L2 until
+// the result overwrites it: one matrix less in LDS lets a fourth frame share the CU.
 // the ray chunk aliases A, V, Y while the affinity is being accumulated
 template <typename T>
 __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
@@ -103,14 +182,14 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     double *V = A + n_max * n_max;
     double *Y = V + n_max * n_max;
     double *X = Y + n_max * n_max;
-    double *W = X + n_max * n_max;
-    double *wts = W + n_max * n_max;
+    double *wts = X + n_max * n_max;
     int *view = reinterpret_cast<int *>(wts + n_max);
     double *rays = A;                               // [person][joint in chunk][7]
     const int lane = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int C = a.C, Kj = a.Kj;
     double *out = a.affinity + f * (int64_t)n_max * n_max;
+    double *W = out;                                // stride n (n*n <= n_max*n_max)
 
     // ---- frame layout ---------------------------------------------------------------------
     int N = 0;
@@ -122,10 +201,11 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     }
     N = min(N, n_max);
     const int n = max(2, (N + 1) & ~1);             // even working size (zero padding)
-    for (int i = lane; i < n * n; i += 64) { X[i] = 0.0; W[i] = 0.0; }
+    for (int i = lane; i < n * n; i += 64) X[i] = 0.0;
     for (int i = N + lane; i < n; i += 64) view[i] = -1 - i;   // padding rows: each its own "view"
     for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
     lds_fence();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // W (global) is read back by other lanes of this wave
     if (N == 0) return;
 
     const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
@@ -181,6 +261,7 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
             W[ii * n + l] += den;
         }
         lds_fence();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     // distance -> affinity (:397-406), circular constraint (:794-795), matchSVT initialisation (:467-475)
     const double thr = a.recon_thr;
@@ -199,15 +280,42 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     for (int i = lane; i < n; i += 64) { X[i * n + i] = 0.0; W[i * n + i] = a.w_sparse; }
     for (int i = lane; i < n * n; i += 64) Y[i] = 0.0;
     lds_fence();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     // ---- matchSVT (:477-505) --------------------------------------------------------------
     double mu = 64.0;
     for (int iter = 0; iter < a.max_iter; ++iter) {
-        // SVT input X + Y/mu (:480), stored column-major for the column rotations; V = I
-        for (int i = lane; i < n * n; i += 64) {
-            const int r = i / n, c = i - r * n;
-            A[c * n + r] = X[i] + Y[i] * 1.0 / mu;
-            V[i] = (r == c) ? 1.0 : 0.0;
+        // SVT input B = X + Y/mu (:480), column-major for the column rotations.
+        // First iteration: A = B, V = I.  Later iterations warm-start from the previous right singular
+        // vectors: B changes little from one ADMM iteration to the next, so A = B . V_prev already has
+        // nearly orthogonal columns and the Jacobi iteration needs ~2 sweeps instead of ~8.
+        if (iter == 0) {
+            for (int i = lane; i < n * n; i += 64) {
+                const int r = i / n, c = i - r * n;
+                A[c * n + r] = X[i] + Y[i] * 1.0 / mu;
+                V[i] = (r == c) ? 1.0 : 0.0;
+            }
+        } else {
+            const int lpr = max(1, 64 / n);                   // lanes per matrix row
+            const int row = lane % n, part = lane / n;
+            const int cpl = (n + lpr - 1) / lpr;              // columns per lane
+            const bool on = part < lpr;
+            for (int cb = 0; cb < cpl; cb += 16) {
+                double acc[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) acc[jj] = 0.0;
+                const int j0 = part * cpl + cb;
+                const int nj = on ? max(0, min(min(16, cpl - cb), n - j0)) : 0;
+                for (int kk = 0; kk < n; ++kk) {
+                    const double bk = X[row * n + kk] + Y[row * n + kk] * 1.0 / mu;   // B[row][kk]
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj)
+                        if (jj < nj) acc[jj] = fma(bk, V[(j0 + jj) * n + kk], acc[jj]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj)
+                    if (jj < nj) A[(j0 + jj) * n + row] = acc[jj];
+            }
         }
         lds_fence();
         jacobi_svd(A, V, n, lane);
@@ -260,7 +368,9 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
         if (pRes > 10 * dRes) mu = 2 * mu;                              // :504
         else if (dRes > 10 * pRes) mu = mu / 2;                         // :505
     }
-    // ---- min_affinity cut (:800) and store ----------------------------------------------------
+    // ---- min_affinity cut (:800) and store (the slab held W until now) ---------------------------
+    for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (int pr = lane; pr < N * N; pr += 64) {
         const int i = pr / N, l = pr - i * N;
         const double v = X[i * n + l];
@@ -269,7 +379,7 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
 }
 
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
-    const size_t lds = (size_t)(5 * a.Nmax * a.Nmax + a.Nmax) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
+    const size_t lds = (size_t)(4 * a.Nmax * a.Nmax + a.Nmax) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
     hipError_t e;
     if (dtype == P2S_F32) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_assoc_kernel<float>),
