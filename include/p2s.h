@@ -127,6 +127,36 @@ int p2s_associate_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, int3
                        const int32_t *n_persons, const int64_t *offsets, const void *kpts,
                        const p2s_assoc_params *params, double *affinity);
 
+/* Parameters of the single-person association (personAssociation.py:177-180). */
+typedef struct p2s_single_params {
+    double reproj_error_threshold;  /* [personAssociation.single_person] reproj_error_threshold_association, px */
+    double likelihood_threshold;    /* [personAssociation] likelihood_threshold_association               */
+    int32_t min_cameras;            /* [triangulation] min_cameras_for_triangulation (>= 1)                */
+    int32_t reserved;
+} p2s_single_params;
+
+/* Single-person association of every frame: replaces persons_combinations (personAssociation.py:67-99)
+ * and best_persons_and_cameras_combination (:154-257, pinhole branch) with triangulate_comb (:102-151):
+ * every combination of one person per camera x every subset of cameras switched off, in the
+ * reference's visiting order and with its carry-over rules.
+ *   n_persons [F][C]  int32   persons per camera (read_json order), each <= P2S_MAX_PERSONS_PER_CAM
+ *   offsets   [F+1]   int64   start of each frame's rows in tracked
+ *   tracked   [rows][3]       (x, y, likelihood) of the tracked keypoint of every person, camera-major,
+ *                             dtype P2S_F32 / P2S_F64
+ * outputs per frame:
+ *   comb [F][C] int32  chosen person per camera, -1 = camera off / nothing detected (NaN in the reference)
+ *   err  [F]    f64    best reprojection error (inf when no combination could be triangulated)
+ *   Q    [F][3] f64    the tracked keypoint in 3D for that combination
+ * The product of the per-camera person counts of a frame must not exceed P2S_MAX_COMBINATIONS. */
+#define P2S_MAX_PERSONS_PER_CAM 16
+#define P2S_MAX_COMBINATIONS (1 << 20)
+int p2s_associate_single_device(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, const int32_t *d_n_persons,
+                                const int64_t *d_offsets, const void *d_tracked, const p2s_single_params *params,
+                                int32_t *d_comb, double *d_err, double *d_Q);
+int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, const int32_t *n_persons,
+                              const int64_t *offsets, const void *tracked, const p2s_single_params *params,
+                              int32_t *comb, double *err, double *Q);
+
 /* Kernel timing on the context's stream with HIP events: begin, enqueue work, end (blocks). */
 int p2s_timing_begin(p2s_ctx *ctx);
 int p2s_timing_end(p2s_ctx *ctx, float *elapsed_ms);

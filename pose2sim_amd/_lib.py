@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get('P2S_LIB') or os.path.join(_HERE, 'csrc', 'libp2s_hip.
 P2S_F32, P2S_F64 = 0, 1
 P2S_MAX_CAMS = 32
 P2S_MAX_PERSONS_TOTAL = 48
+P2S_MAX_PERSONS_PER_CAM = 16
+P2S_MAX_COMBINATIONS = 1 << 20
 
 
 class TriParams(C.Structure):
@@ -33,6 +35,13 @@ class AssocParams(C.Structure):
                 ('w_sparse', C.c_double)]
 
 
+class SingleParams(C.Structure):
+    _fields_ = [('reproj_error_threshold', C.c_double),
+                ('likelihood_threshold', C.c_double),
+                ('min_cameras', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/p2s.h declares
 SIGNATURES = {
     'p2s_version': (C.c_int, []),
@@ -51,6 +60,10 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.POINTER(AssocParams), C.c_void_p]),
     'p2s_associate_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.POINTER(AssocParams), C.c_void_p]),
+    'p2s_associate_single_device': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(SingleParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'p2s_associate_single_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(SingleParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     'p2s_timing_begin': (C.c_int, [C.c_void_p]),
     'p2s_timing_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     'p2s_tri_geometry': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

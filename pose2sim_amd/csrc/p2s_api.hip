@@ -482,6 +482,80 @@ int p2s_associate_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, int3
     return P2S_OK;
 }
 
+static int check_single(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, const p2s_single_params *p) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (ctx->n_cams <= 0) return fail(P2S_ERR_NO_CALIB, "p2s_set_calibration has not been called");
+    if (!p) return fail(P2S_ERR_INVALID_ARG, "null params");
+    if (n_frames < 0 || n_frames > 0x7fffffffLL) return fail(P2S_ERR_INVALID_ARG, "bad frame count");
+    if (dtype != P2S_F32 && dtype != P2S_F64) return fail(P2S_ERR_INVALID_ARG, "dtype must be P2S_F32 or P2S_F64");
+    if (p->min_cameras < 1) return fail(P2S_ERR_INVALID_ARG, "min_cameras must be >= 1");
+    return P2S_OK;
+}
+
+int p2s_associate_single_device(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, const int32_t *d_n_persons,
+                                const int64_t *d_offsets, const void *d_tracked, const p2s_single_params *params,
+                                int32_t *d_comb, double *d_err, double *d_Q) {
+    int rc = check_single(ctx, n_frames, dtype, params);
+    if (rc != P2S_OK) return rc;
+    if (n_frames == 0) return P2S_OK;
+    if (!d_n_persons || !d_offsets || !d_tracked || !d_comb || !d_err || !d_Q)
+        return fail(P2S_ERR_INVALID_ARG, "null device pointer");
+    P2sSingleArgs a{};
+    a.n_persons = d_n_persons; a.offsets = d_offsets; a.tracked = d_tracked;
+    a.comb = d_comb; a.err = d_err; a.Q = d_Q;
+    a.cams = ctx->d_cams; a.binom = ctx->d_binom;
+    a.n_frames = n_frames; a.C = ctx->n_cams; a.min_cams = params->min_cameras;
+    a.thr = params->reproj_error_threshold; a.lik_thr = params->likelihood_threshold;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(p2s_launch_single(a, dtype, ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, const int32_t *n_persons,
+                              const int64_t *offsets, const void *tracked, const p2s_single_params *params,
+                              int32_t *comb, double *err, double *Q) {
+    int rc = check_single(ctx, n_frames, dtype, params);
+    if (rc != P2S_OK) return rc;
+    if (n_frames == 0) return P2S_OK;
+    if (!n_persons || !offsets || !comb || !err || !Q) return fail(P2S_ERR_INVALID_ARG, "null host pointer");
+    const int C = ctx->n_cams;
+    int64_t rows = 0;
+    for (int64_t f = 0; f < n_frames; ++f) {       // operand shapes are checked before anything is launched
+        if (offsets[f] != rows) return fail(P2S_ERR_INVALID_ARG, "offsets[%lld] does not match n_persons", (long long)f);
+        double prod = 1.0;
+        for (int c = 0; c < C; ++c) {
+            const int32_t n = n_persons[f * C + c];
+            if (n < 0 || n > P2S_MAX_PERSONS_PER_CAM)
+                return fail(P2S_ERR_INVALID_ARG, "frame %lld camera %d: %d persons outside [0, %d]", (long long)f, c, n, P2S_MAX_PERSONS_PER_CAM);
+            rows += n;
+            prod *= n > 0 ? n : 1;
+        }
+        if (prod > (double)P2S_MAX_COMBINATIONS)
+            return fail(P2S_ERR_INVALID_ARG, "frame %lld: %.0f person combinations exceed %d", (long long)f, prod, P2S_MAX_COMBINATIONS);
+    }
+    if (offsets[n_frames] != rows) return fail(P2S_ERR_INVALID_ARG, "offsets[F] does not match n_persons");
+    if (rows > 0 && !tracked) return fail(P2S_ERR_INVALID_ARG, "null tracked");
+    const size_t elem = dtype == P2S_F32 ? 4 : 8;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.ensure(std::max<size_t>(16, (size_t)rows * 3 * elem))) != P2S_OK) return rc;
+    if ((rc = ctx->aux0.ensure((size_t)n_frames * C * 4)) != P2S_OK) return rc;
+    if ((rc = ctx->aux1.ensure((size_t)(n_frames + 1) * 8)) != P2S_OK) return rc;
+    if ((rc = ctx->mask.ensure((size_t)n_frames * C * 4)) != P2S_OK) return rc;
+    if ((rc = ctx->err.ensure((size_t)n_frames * 8)) != P2S_OK) return rc;
+    if ((rc = ctx->q.ensure((size_t)n_frames * 24)) != P2S_OK) return rc;
+    if (rows > 0) HIP_TRY(hipMemcpyAsync(ctx->in.p, tracked, (size_t)rows * 3 * elem, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->aux0.p, n_persons, (size_t)n_frames * C * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->aux1.p, offsets, (size_t)(n_frames + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = p2s_associate_single_device(ctx, n_frames, dtype, (const int32_t *)ctx->aux0.p, (const int64_t *)ctx->aux1.p,
+                                     ctx->in.p, params, (int32_t *)ctx->mask.p, (double *)ctx->err.p, (double *)ctx->q.p);
+    if (rc != P2S_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(comb, ctx->mask.p, (size_t)n_frames * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(err, ctx->err.p, (size_t)n_frames * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(Q, ctx->q.p, (size_t)n_frames * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
 int p2s_timing_begin(p2s_ctx *ctx) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));

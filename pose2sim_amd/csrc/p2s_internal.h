@@ -64,6 +64,21 @@ struct P2sAssocArgs {
 
 hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
                           hipEvent_t k1_done);
+struct P2sSingleArgs {
+    const int32_t *n_persons;   // [F][C]
+    const int64_t *offsets;     // [F+1]
+    const void *tracked;        // [rows][3]
+    int32_t *comb;              // [F][C]
+    double *err;                // [F]
+    double *Q;                  // [F][3]
+    const P2sCam *cams;
+    const uint32_t *binom;
+    int64_t n_frames;
+    int32_t C, min_cams;
+    double thr, lik_thr;
+};
+hipError_t p2s_launch_single(const P2sSingleArgs &a, int dtype, hipStream_t s);
+
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s);
 
 #endif

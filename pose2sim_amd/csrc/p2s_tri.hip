@@ -49,6 +49,8 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return (e == e) ? r : r0;
 }
 
+__device__ __forceinline__ double p2s_inline_rcp(double d) { return fast_rcp(d); }
+
 // sqrt(s), s >= 0, to ~1 ulp: v_rsq_f64 seed, one Goldschmidt step, one residual correction.
 __device__ __forceinline__ double fast_sqrt(double s) {
     const double y = __builtin_amdgcn_rsq(s);
@@ -1007,6 +1009,170 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next records overwrite this wave's LDS region
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-person association (personAssociation.py:67-257, pinhole branch): one wave per frame.
+// Lane i of a pass takes combination #(pass*64 + i) of "one person per camera" (itertools.product
+// order, last camera fastest), switches off the cameras whose tracked-keypoint likelihood is below the
+// threshold (:212-213), and evaluates every subset of `extra` further cameras switched off
+// (itertools.combinations over the active cameras, :219-231) with the weighted DLT + reprojection
+// error of kernel 1.  The reference's sequential rules are then applied across the lanes in
+// combination order: the scan of a level stops at the first combination below the threshold
+// (:242-243), `error_min` is that of the LAST combination looked at (:233) and drives the while loop
+// (:192), the best solution is kept across levels with a strict '<' (:237).
+// LDS: [tracked keypoints: C x P2S_MAX_PERSONS_PER_CAM x 3 doubles][ids: 64 x C bytes][binom]
+template <typename T>
+__global__ void __launch_bounds__(64) p2s_single_kernel(const P2sSingleArgs a) {
+    constexpr int PMAX = 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = a.C;
+    double *tk = reinterpret_cast<double *>(smem);                                  // [C][PMAX][3]
+    uint8_t *ids = smem + (size_t)C * PMAX * 3 * sizeof(double);                    // [64][C]
+    uint32_t *sBinom = reinterpret_cast<uint32_t *>(smem + (((size_t)C * PMAX * 24 + 64 * C + 15) / 16) * 16);
+    cam_cptr cams = (cam_cptr)a.cams;
+    const int lane = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const double thr = a.thr;
+
+    for (int i = lane; i < 33 * 33; i += 64) sBinom[i] = a.binom[i];
+    // persons per camera and their tracked keypoints
+    const T *src = reinterpret_cast<const T *>(a.tracked) + a.offsets[f] * 3;
+    int row = 0;
+    uint32_t present = 0;
+    for (int c = 0; c < C; ++c) {
+        const int pc = min(a.n_persons[f * C + c], PMAX);
+        if (pc > 0) present |= 1u << c;
+        for (int i = lane; i < pc * 3; i += 64) tk[(c * PMAX) * 3 + i] = (double)src[row * 3 + i];
+        row += pc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t n_comb = 1;
+    for (int c = 0; c < C; ++c) n_comb *= (uint32_t)max(1, min(a.n_persons[f * C + c], PMAX));
+    const int missing = C - __popc(present);
+
+    double error_min = kInf;
+    double best_e = kInf, best_q0 = d_nan(), best_q1 = d_nan(), best_q2 = d_nan();
+    uint32_t best_ci = 0xffffffffu, best_kept = 0;
+    uint8_t *my_ids = ids + (size_t)lane * C;
+
+    for (int extra = 0; error_min > thr && C - (missing + extra) >= a.min_cams; ++extra) {
+        bool stop = false;
+        for (uint32_t c0 = 0; c0 < n_comb && !stop; c0 += 64) {
+            const uint32_t ci = c0 + lane;
+            const bool in_range = ci < n_comb;
+            // decode the combination (itertools.product: the last camera varies fastest)
+            uint32_t rem = in_range ? ci : 0u, active = 0;
+            for (int c = C - 1; c >= 0; --c) {
+                const uint32_t rc = (uint32_t)max(1, min(a.n_persons[f * C + c], PMAX));
+                const uint32_t id = rem % rc;
+                rem /= rc;
+                my_ids[c] = (uint8_t)id;
+                if ((present >> c) & 1u) {
+                    const double lk = tk[(c * PMAX + id) * 3 + 2];
+                    if (!(lk < a.lik_thr) && lk != 0.0) active |= 1u << c;        // :212-213
+                }
+            }
+            const int nact = __popc(active);
+            bool valid = in_range && nact >= a.min_cams && extra < nact;          // :216-217, :234 (all NaN)
+            // every subset of `extra` active cameras switched off
+            double ce = kInf, cq0 = d_nan(), cq1 = d_nan(), cq2 = d_nan();
+            uint32_t ckept = 0;
+            bool first = true;
+            const uint32_t nsub = valid ? sBinom[nact * 33 + extra] : 0u;
+            uint32_t max_sub = nsub;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) max_sub = max(max_sub, (uint32_t)__shfl_xor((int)max_sub, off, 64));
+            for (uint32_t r = 0; r < max_sub; ++r) {
+                const bool go = valid && r < nsub;
+                uint32_t kept = active;
+                if (go) {
+                    const uint32_t S = unrank_subset(r, nact, extra, sBinom);     // positions among the active cameras
+                    uint32_t act = active;
+                    for (int pos = 0; act; ++pos, act &= act - 1)
+                        if ((S >> pos) & 1u) kept &= ~(act & (0u - act));
+                }
+                double N[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) N[i] = 0.0;
+                for (int c = 0; c < C; ++c) {
+                    const double *o = tk + ((size_t)c * PMAX + my_ids[c]) * 3;
+                    const bool k = go && ((kept >> c) & 1u);
+                    accum_camera<1>(N, cams[c].P, k ? o[0] : 0.0, k ? o[1] : 0.0, k ? o[2] : 0.0);
+                }
+                double q[3];
+                smallest_eigvec(N, q);
+                if (__popc(kept) < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
+                double sum = 0.0;
+                for (int c = 0; c < C; ++c) {
+                    const double *o = tk + ((size_t)c * PMAX + my_ids[c]) * 3;
+                    const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], o[0], o[1]);
+                    sum += (go && ((kept >> c) & 1u)) ? d : 0.0;
+                }
+                // One camera left: weighted_triangulation (common.py:327-356) returns NaN for fewer than 4 rows
+                // and euclidean_distance turns the all-NaN difference into inf.
+                const double e = __popc(kept) < 2 ? kInf : sum * p2s_inline_rcp((double)__popc(kept));
+                if (go && (first || e < ce)) { ce = e; cq0 = q[0]; cq1 = q[1]; cq2 = q[2]; ckept = kept; first = false; }
+            }
+            // the reference's sequential scan over the combinations of this pass, in order
+            const unsigned long long vmask = __ballot(valid);
+            const unsigned long long below = __ballot(valid && ce < thr);
+            const int brk = below ? __builtin_ctzll(below) : 64;
+            const unsigned long long seen = (brk >= 63) ? vmask : (vmask & ((2ull << brk) - 1ull));
+            if (seen != 0ull) {
+                // lowest error among the combinations looked at, earliest one on ties
+                double me = ((seen >> lane) & 1ull) ? ce : kInf;
+                uint32_t ml = ((seen >> lane) & 1ull) ? (uint32_t)lane : 0xffffffffu;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double oe = shfl_d(me, lane ^ off);
+                    const uint32_t ol = __shfl(ml, lane ^ off, 64);
+                    const bool take = (ol != 0xffffffffu) && (ml == 0xffffffffu || oe < me || (oe == me && ol < ml));
+                    if (take) { me = oe; ml = ol; }
+                }
+                if (ml != 0xffffffffu && me < best_e) {                          // :237 strict
+                    best_e = me;
+                    best_q0 = shfl_d(cq0, (int)ml); best_q1 = shfl_d(cq1, (int)ml); best_q2 = shfl_d(cq2, (int)ml);
+                    best_kept = __shfl(ckept, (int)ml, 64);
+                    best_ci = c0 + ml;
+                }
+                const int last = 63 - __builtin_clzll(seen);
+                error_min = shfl_d(ce, last);                                      // :233: the last one looked at
+            }
+            stop = below != 0ull;                                                  // :242-243
+        }
+    }
+
+    // ---- result: chosen person per camera, -1 where the camera is off -------------------------------
+    if (lane < C) {
+        int id = -1;
+        if (best_ci != 0xffffffffu) {
+            uint32_t rem = best_ci;
+            int mine = 0;
+            for (int c = C - 1; c >= 0; --c) {
+                const uint32_t rc = (uint32_t)max(1, min(a.n_persons[f * C + c], PMAX));
+                if (c == lane) mine = (int)(rem % rc);
+                rem /= rc;
+            }
+            id = ((best_kept >> lane) & 1u) ? mine : -1;
+        }
+        a.comb[f * C + lane] = id;
+    }
+    if (lane == 0) {
+        a.err[f] = best_e;
+        a.Q[f * 3 + 0] = best_q0; a.Q[f * 3 + 1] = best_q1; a.Q[f * 3 + 2] = best_q2;
+    }
+}
+
+hipError_t p2s_launch_single(const P2sSingleArgs &a, int dtype, hipStream_t s) {
+    const size_t lds = (((size_t)a.C * 16 * 24 + 64 * a.C + 15) / 16) * 16 + 33 * 33 * 4;
+    if (dtype == 0)
+        hipLaunchKernelGGL((p2s_single_kernel<float>), dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
+    else
+        hipLaunchKernelGGL((p2s_single_kernel<double>), dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------

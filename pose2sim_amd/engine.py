@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import P2S_F32, P2S_F64, AssocParams, P2sError, TriParams  # noqa: F401
+from ._lib import P2S_F32, P2S_F64, AssocParams, P2sError, SingleParams, TriParams  # noqa: F401
 
 
 def _ptr(a):
@@ -161,6 +161,28 @@ class Engine:
                                                 _ptr(offsets), _ptr(kpts) if kpts.size else None, C.byref(params),
                                                 _ptr(aff)))
         return aff
+
+    def associate_single(self, n_persons, tracked, reproj_thr, lik_thr, min_cams):
+        """Single-person association (personAssociation.py:154-257).  n_persons [F][C] int, tracked [rows][3]
+        = (x, y, likelihood) of the tracked keypoint of every detected person, camera-major per frame.
+        Returns comb int32 [F][C] (chosen person per camera, -1 = camera off), err [F] (inf: none), Q [F][3]."""
+        n_persons = np.ascontiguousarray(np.asarray(n_persons, dtype=np.int32))
+        F, Cn = n_persons.shape
+        if Cn != self.n_cams:
+            raise P2sError(f'n_persons has {Cn} cameras; calibration has {self.n_cams}')
+        tracked, dtype = as_packed(np.asarray(tracked).reshape(-1, 3))
+        offsets = np.zeros(F + 1, dtype=np.int64)
+        np.cumsum(n_persons.sum(axis=1, dtype=np.int64), out=offsets[1:])
+        if tracked.shape[0] != offsets[-1]:
+            raise P2sError(f'tracked has {tracked.shape[0]} rows; n_persons sums to {offsets[-1]}')
+        comb = np.full((F, Cn), -1, dtype=np.int32)
+        err = np.full(F, np.inf)
+        Q = np.full((F, 3), np.nan)
+        prm = SingleParams(float(reproj_thr), float(lik_thr), int(min_cams), 0)
+        _lib.check(self._lib.p2s_associate_single_host(self._h, F, dtype, _ptr(n_persons), _ptr(offsets),
+                                                       _ptr(tracked) if tracked.size else None, C.byref(prm),
+                                                       _ptr(comb), _ptr(err), _ptr(Q)))
+        return comb, err, Q
 
     def associate_device(self, F, Kj, n_max, dtype, d_n_persons, d_offsets, d_kpts, params, d_aff):
         _lib.check(self._lib.p2s_associate_device(self._h, int(F), int(Kj), int(n_max), int(dtype),

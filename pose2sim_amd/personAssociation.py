@@ -1,13 +1,17 @@
 """Person association stage: drop-in for the reference's ``associate_all(config_dict)``
-(personAssociation.py:642-808), multi-person branch, with rays + affinity + matchSVT on the MI355X.
+(personAssociation.py:642-808), both branches, on the MI355X.
 
 Per frame the reference computes Pluecker rays, the pairwise epipolar affinity, ~20 full SVDs
 (matchSVT) and then extracts proposals; here every frame of the trial goes to the HIP engine in ONE
 call and only the order-sensitive proposal extraction (person_index_per_cam, :512-549, exact
 ``np.unique`` / ``argsort`` semantics) and the JSON rewrite (:552-580) stay on the host.
 
-The single-person branch (brute-force person x camera-subset search on one tracked keypoint,
-:67-257) is not part of this engine yet ("next").
+Single-person branch (:67-257): the brute-force search over "one person per camera" x "cameras
+switched off" on one tracked keypoint runs in the engine for every frame at once
+(``Engine.associate_single``); the host only gathers the tracked keypoint of every detected person and
+rewrites the JSON files.  With ``undistort_points`` the reference's own single-person code cannot run
+(triangulate_comb :130 indexes the per-camera lists with ``range(len(Q_comb))`` = 4 entries and raises
+for fewer than 4 kept cameras), so that combination is refused here with a clear message.
 """
 import json
 import logging
@@ -17,7 +21,7 @@ import numpy as np
 
 from . import calib as calib_mod
 from . import poseio, skeletons
-from ._lib import P2S_MAX_PERSONS_TOTAL
+from ._lib import P2S_MAX_COMBINATIONS, P2S_MAX_PERSONS_PER_CAM, P2S_MAX_PERSONS_TOTAL
 
 
 def _make_engine():
@@ -69,15 +73,95 @@ def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
             os.remove(json_tracked_files_f[cam])
 
 
-def recap_tracking(config_dict):
-    """Multi-person lines of personAssociation.py:583-639."""
+def recap_tracking(config_dict, error=0, nb_cams_excluded=0):
+    """personAssociation.py:583-639."""
     project_dir = config_dict.get('project').get('project_dir')
+    session_dir = os.path.realpath(os.path.join(project_dir, '..'))
+    session_dir = session_dir if 'Config.toml' in os.listdir(session_dir) else os.getcwd()
+    multi_person = config_dict.get('project').get('multi_person')
+    likelihood_threshold_association = config_dict.get('personAssociation').get('single_person').get('likelihood_threshold_association', 0.3)
+    tracked_keypoint = config_dict.get('personAssociation').get('single_person').get('tracked_keypoint')
+    error_threshold_tracking = config_dict.get('personAssociation').get('single_person').get('reproj_error_threshold_association')
     reconstruction_error_threshold = config_dict.get('personAssociation').get('multi_person').get('reconstruction_error_threshold')
     min_affinity = config_dict.get('personAssociation').get('multi_person').get('min_affinity')
     poseTracked_dir = os.path.join(project_dir, 'pose-associated')
-    logging.info(f'\n--> A person was reconstructed if the lines from cameras to their keypoints intersected within {reconstruction_error_threshold} m and if the calculated affinity stayed above {min_affinity}.')
-    logging.info('--> Beware that people were sorted across cameras, but not across frames. This will be done in the triangulation stage.')
+    if not multi_person:
+        calib = calib_mod.load_toml(calib_mod.find_calibration_file(session_dir))
+        calib_cam1 = calib[calib_mod.camera_keys(calib)[0]]
+        fm = calib_cam1['matrix'][0][0]
+        Dm = float(np.sqrt(np.sum(np.array(calib_cam1['translation'], dtype=np.float64) ** 2)))
+        mean_error_px = np.around(np.nanmean(error), decimals=1)
+        mean_error_mm = np.around(mean_error_px * Dm / fm * 1000, decimals=1)
+        mean_cam_off_count = np.around(np.mean(nb_cams_excluded), decimals=2)
+        logging.info(f'\n--> Mean reprojection error for {tracked_keypoint} point on all frames is {mean_error_px} px, which roughly corresponds to {mean_error_mm} mm. ')
+        logging.info(f'--> In average, {mean_cam_off_count} cameras had to be excluded to reach the demanded {error_threshold_tracking} px error threshold after excluding points with likelihood below {likelihood_threshold_association}.')
+    else:
+        logging.info(f'\n--> A person was reconstructed if the lines from cameras to their keypoints intersected within {reconstruction_error_threshold} m and if the calculated affinity stayed above {min_affinity}.')
+        logging.info('--> Beware that people were sorted across cameras, but not across frames. This will be done in the triangulation stage.')
     logging.info(f'\nTracked json files are stored in {os.path.realpath(poseTracked_dir)}.')
+
+
+def count_persons_for_combinations(path):
+    """persons_combinations' own count (personAssociation.py:84-91): people whose x values are not all NaN;
+    0 when the file cannot be read."""
+    try:
+        people = poseio._load(path)['people']
+        return len([p for p in people if not all(np.isnan(p['pose_keypoints_2d'][::3]))])
+    except Exception:
+        return 0
+
+
+def _associate_single_person(config_dict, frames_src, frames_dst, n_cams, P_all, calib_params):
+    """Single-person branch of associate_all (:745-755, :772-781) over every frame in one engine call."""
+    pose_model = config_dict.get('pose').get('pose_model')
+    tracked_keypoint = config_dict.get('personAssociation').get('single_person').get('tracked_keypoint')
+    error_threshold_tracking = config_dict.get('personAssociation').get('single_person').get('reproj_error_threshold_association')
+    likelihood_threshold = config_dict.get('personAssociation').get('likelihood_threshold_association')
+    min_cameras_for_triangulation = config_dict.get('triangulation').get('min_cameras_for_triangulation')
+    if config_dict.get('triangulation').get('undistort_points'):
+        raise NotImplementedError('single-person association with undistort_points: the reference itself fails there '
+                                  '(personAssociation.py:130); run the association on the distorted points.')
+    try:
+        tracked_keypoint_id = skeletons.node_id_by_name(pose_model, tracked_keypoint, config_dict)
+        assert tracked_keypoint_id                       # id None and id 0 both land in the fallback, :749
+    except Exception:
+        tracked_keypoint_id = 0
+        rows = skeletons.model_rows(pose_model, config_dict)
+        tracked_keypoint_name = next(r[0] for r in rows if r[1] == 0)
+        logging.warning(f'{tracked_keypoint} not found in {pose_model}, consider editing tracked_keypoint in Config.toml. Tracking {tracked_keypoint_name} instead.')
+    k3 = tracked_keypoint_id * 3
+
+    # the tracked keypoint of every candidate person: index i of a camera is read_json's i-th person (:200-202)
+    F = len(frames_src)
+    n_persons = np.zeros((F, n_cams), dtype=np.int32)
+    tracked = []
+    for fi, src in enumerate(frames_src):
+        for c in range(n_cams):
+            n = count_persons_for_combinations(src[c])
+            people = poseio.read_people(src[c]) if n else []
+            n_persons[fi, c] = n
+            for i in range(n):
+                v = list(people[i][k3:k3 + 3]) if i < len(people) else []
+                tracked.append(v if len(v) == 3 else [np.nan, np.nan, np.nan])
+    if n_persons.max(initial=0) > P2S_MAX_PERSONS_PER_CAM:
+        raise ValueError(f'a camera holds more than {P2S_MAX_PERSONS_PER_CAM} detections in one frame')
+    if np.prod(np.maximum(n_persons, 1).astype(np.float64), axis=1).max(initial=0) > P2S_MAX_COMBINATIONS:
+        raise ValueError(f'a frame holds more than {P2S_MAX_COMBINATIONS} person combinations')
+    tracked = np.asarray(tracked, dtype=np.float64).reshape(-1, 3)
+
+    engine = _make_engine()
+    engine.set_calibration(P_all, calib_params)
+    comb, err, _ = engine.associate_single(n_persons, tracked, error_threshold_tracking, likelihood_threshold,
+                                           min_cameras_for_triangulation)
+
+    error_min_tot, cameras_off_tot = [], []
+    for fi in range(F):
+        proposal = np.where(comb[fi] < 0, np.nan, comb[fi].astype(float))
+        if not np.isinf(err[fi]):
+            error_min_tot.append(err[fi])
+        cameras_off_tot.append(float(np.count_nonzero(np.isnan(proposal))))
+        rewrite_json_files(frames_dst[fi], frames_src[fi], [proposal], n_cams)
+    return error_min_tot, cameras_off_tot
 
 
 def associate_all(config_dict):
@@ -133,15 +217,22 @@ def associate_all(config_dict):
                     Found {len(P_all)} cameras in the calibration file,\
                     and {n_cams} cameras based on the number of pose folders.')
 
+    maps = poseio.frame_file_map(json_files_names)
+    frames = range(*f_range)
+
     if not multi_person:
         logging.info('\nSingle-person analysis selected.')
-        raise NotImplementedError('single-person association (personAssociation.py:67-257) is not part of this '
-                                  'engine yet; set project.multi_person = true or run that mode with the reference.')
+        # (always from pose/: the reference's os.path.exist typo at :764)
+        names = [[maps[c].get(f, 'none') for c in range(n_cams)] for f in frames]
+        frames_src = [[os.path.join(pose_dir, json_dirs_names[c], nm[c]) for c in range(n_cams)] for nm in names]
+        frames_dst = [[os.path.join(poseTracked_dir, json_dirs_names[c], nm[c]) for c in range(n_cams)] for nm in names]
+        error_min_tot, cameras_off_tot = _associate_single_person(config_dict, frames_src, frames_dst, n_cams,
+                                                                  P_all, calib_params)
+        recap_tracking(config_dict, error_min_tot, cameras_off_tot)
+        return
     logging.info('\nMulti-person analysis selected.')
 
     # ---- read every frame (always from pose/: the reference's os.path.exist typo at :764) --------
-    maps = poseio.frame_file_map(json_files_names)
-    frames = range(*f_range)
     src_files, dst_files, people_all = [], [], []
     n_persons = np.zeros((len(frames), n_cams), dtype=np.int32)
     Kj3 = None

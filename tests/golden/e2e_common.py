@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 from pose2sim_amd import calib as calib_mod
-from pose2sim_amd import poseio
+from pose2sim_amd import poseio, synth
 
 
 def base_config(project_dir, multi_person, **tri):
@@ -88,3 +88,30 @@ def people_from_xyl(xyl, ids, n_json_kpts, drop=None):
             per_cam.append(people)
         out.append(per_cam)
     return out
+
+
+def make_single_scene(F, C, Kj, seed, n_distract=2):
+    """One person of interest seen by every camera plus random distractors (inconsistent across views),
+    persons in random order per camera; some low-confidence detections, some empty cameras."""
+    rng = np.random.default_rng(seed)
+    cams = synth.make_cameras(C, seed=seed)
+    Q3d = synth.make_points3d(F, 1 + n_distract * C, Kj, seed=seed)
+    xyl = synth.make_observations(Q3d, cams, seed=seed, noise_px=2.0, p_lowlik=0.0, p_outlier=0.0, p_missing_cam=0.0)
+    frames = []
+    for f in range(F):
+        per_cam = []
+        for c in range(C):
+            if rng.random() < 0.04:
+                per_cam.append([])
+                continue
+            people = [xyl[f, 0, c].astype(np.float64).copy()]
+            for d in range(rng.integers(0, n_distract + 1)):
+                people.append(xyl[f, 1 + c * n_distract + d, c].astype(np.float64).copy())   # seen by this camera only
+            if rng.random() < 0.10:                     # the real person is poorly detected in this view
+                people[0][:, 2] = rng.uniform(0.05, 0.25)
+            if rng.random() < 0.05:                     # or badly localised
+                people[0][:, :2] += rng.normal(0, 80, 2)
+            order = rng.permutation(len(people))
+            per_cam.append([people[i].ravel() for i in order])
+        frames.append(per_cam)
+    return cams, frames

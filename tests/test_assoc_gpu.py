@@ -4,9 +4,14 @@ Against the frames recorded from the reference (tests/golden/assoc_frames.npz): 
 matchSVT matrix within 1e-7 and, from it, IDENTICAL proposals (person_index_per_cam on the host).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+from pose2sim_amd import synth  # noqa: E402
+from pose2sim_amd._lib import P2sError  # noqa: E402
 
 from test_oracle_golden import _assoc_groups, assoc_frames_of
 
@@ -104,3 +109,75 @@ def test_partial_iterations_match_oracle(engine, golden_dir):
                 assert d <= 1e-9, (i, it, f, d)
     assert worst > 0.0          # the comparison was on continuous values
     print(f'partial iterations: worst |d| = {worst:.3e}')
+
+
+# ---- single-person mode ---------------------------------------------------------------------------
+def _single_inputs(per_frame, kid):
+    n_persons = np.array([[len(p) for p in per_cam] for per_cam in per_frame], dtype=np.int32)
+    tracked = np.array([np.asarray(p)[kid * 3:kid * 3 + 3] for per_cam in per_frame for people in per_cam for p in people],
+                       dtype=np.float64).reshape(-1, 3)
+    return n_persons, tracked
+
+
+def _check_single(comb, err, Q, want_comb, want_err, want_Q, tag):
+    """Identical person / camera choice; error within 1e-6 px (a 1e-10 m change of Q moves a pixel error by
+    ~1e-7 px at these focal lengths / distances); Q within 1e-7 m (north_star)."""
+    for f in range(len(err)):
+        wc = np.where(np.isnan(want_comb[f]), -1, want_comb[f]).astype(np.int32)
+        assert np.array_equal(comb[f], wc), (tag, f, comb[f], wc)
+        if np.isinf(want_err[f]):
+            assert np.isinf(err[f]) and np.isnan(Q[f]).all(), (tag, f)
+            continue
+        assert abs(err[f] - want_err[f]) <= 1e-6 * max(1.0, abs(want_err[f])), (tag, f, err[f], want_err[f])
+        assert np.allclose(Q[f], want_Q[f], rtol=0, atol=1e-7), (tag, f, Q[f], want_Q[f])
+
+
+@pytest.mark.gpu
+def test_single_person_matches_reference_goldens(engine, golden_dir):
+    """Per-frame best error / combination / 3D point recorded from the reference's
+    best_persons_and_cameras_combination (tests/golden/make_golden_e2e_single.py)."""
+    from test_oracle_golden import single_frames_of
+    z = np.load(os.path.join(golden_dir, 'e2e_single.npz'))
+    for name in [str(n) for n in z['cases']]:
+        P, frames = single_frames_of(z, name)
+        eng = engine
+        eng.set_calibration(np.array(P))
+        n_persons, tracked = _single_inputs(frames, 18)
+        comb, err, Q = eng.associate_single(n_persons, tracked, float(z[f'{name}_thr']), 0.3, int(z[f'{name}_min_cams']))
+        _check_single(comb, err, Q, z[f'{name}_best_comb'], z[f'{name}_best_err'], z[f'{name}_best_Q'], name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('C,min_cams,thr,seed', [(3, 2, 8.0, 1), (4, 2, 4.0, 2), (6, 3, 6.0, 3), (8, 4, 5.0, 4), (5, 2, 0.5, 5)])
+def test_single_person_matches_oracle_on_random_trials(engine, C, min_cams, thr, seed):
+    """More cameras, tighter thresholds (deeper camera-removal levels, more than 64 combinations per
+    frame, frames where nothing qualifies) against the pinned oracle."""
+    from e2e_common import make_single_scene
+    from oracle import association_single_ref as sr
+    cams, frames = make_single_scene(24, C, 26, 100 + seed, n_distract=3 if C <= 5 else 1)
+    P = synth.projection_matrices(cams)
+    eng = engine
+    eng.set_calibration(np.array(P))
+    n_persons, tracked = _single_inputs(frames, 18)
+    comb, err, Q = eng.associate_single(n_persons, tracked, thr, 0.3, min_cams)
+    want_c, want_e, want_q = [], [], []
+    for per_cam in frames:
+        e, cb, q = sr.best_persons_and_cameras(per_cam, sr.persons_combinations([len(p) for p in per_cam]), P, 18, thr,
+                                               min_cams, 0.3)
+        want_c.append(cb); want_e.append(e); want_q.append(q)
+    _check_single(comb, err, Q, np.array(want_c), np.array(want_e), np.array(want_q), f'C{C}')
+
+
+@pytest.mark.gpu
+def test_single_person_edge_cases(engine):
+    cams = synth.make_cameras(4, seed=9)
+    eng = engine
+    eng.set_calibration(np.array(synth.projection_matrices(cams)))
+    # no frames; a frame with no detections at all; a frame with one camera only
+    comb, err, Q = eng.associate_single(np.zeros((0, 4), np.int32), np.zeros((0, 3)), 10.0, 0.3, 2)
+    assert comb.shape == (0, 4) and err.shape == (0,)
+    n_persons = np.array([[0, 0, 0, 0], [1, 0, 0, 0]], dtype=np.int32)
+    comb, err, Q = eng.associate_single(n_persons, np.array([[100.0, 100.0, 0.9]]), 10.0, 0.3, 2)
+    assert (comb == -1).all() and np.isinf(err).all() and np.isnan(Q).all()
+    with pytest.raises(P2sError):
+        eng.associate_single(np.full((1, 4), 17, np.int32), np.zeros((68, 3)), 10.0, 0.3, 2)

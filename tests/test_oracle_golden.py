@@ -129,3 +129,39 @@ def test_association_oracle_matches_reference(golden_dir):
             assert np.array_equal(props, g['proposals'][f, :k], equal_nan=True), (i, f)
             n += 1
     assert n > 200
+
+
+# ------------------------------------------------------------------------------------------------
+def single_frames_of(z, name):
+    """Per-frame people lists and calibration of a single-person association fixture."""
+    from pose2sim_amd import cvmath
+    C = z[f'{name}_n_persons'].shape[1]
+    K = z[f'{name}_K']
+    P = [np.hstack([K[c], np.zeros((3, 1))]) @ np.vstack([np.hstack([cvmath.rodrigues(z[f'{name}_R'][c]), z[f'{name}_T'][c].reshape(3, 1)]), [0, 0, 0, 1]])
+         for c in range(C)]
+    frames, row = [], 0
+    for f in range(z[f'{name}_n_persons'].shape[0]):
+        per_cam = []
+        for c in range(C):
+            n = int(z[f'{name}_n_persons'][f, c])
+            per_cam.append([z[f'{name}_kpts'][row + i].ravel() for i in range(n)])
+            row += n
+        frames.append(per_cam)
+    return P, frames
+
+
+def test_single_person_oracle_matches_reference(golden_dir):
+    from oracle import association_single_ref as sr
+    z = np.load(os.path.join(golden_dir, 'e2e_single.npz'))
+    n = 0
+    for name in z['cases']:
+        name = str(name)
+        P, frames = single_frames_of(z, name)
+        for f, per_cam in enumerate(frames):
+            combos = sr.persons_combinations([len(p) for p in per_cam])
+            e, cb, Q = sr.best_persons_and_cameras(per_cam, combos, P, 18, float(z[f'{name}_thr']), int(z[f'{name}_min_cams']), 0.3)
+            assert np.array_equal(cb, z[f'{name}_best_comb'][f], equal_nan=True), (name, f, cb, z[f'{name}_best_comb'][f])
+            assert abs(e - z[f'{name}_best_err'][f]) <= 1e-9 * max(1.0, abs(e)), (name, f)
+            assert np.allclose(Q, z[f'{name}_best_Q'][f], rtol=0, atol=1e-9, equal_nan=True), (name, f)
+            n += 1
+    assert n == 50
