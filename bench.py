@@ -38,6 +38,11 @@ CONFIGS = {
     'cfg3': dict(workload='Demo_MultiPerson-style: 8 cams x 4 persons x HALPE_26 x 50k frames, epipolar association (BASELINE configs[2])',
                  F=50_000, C=8, model='HALPE_26', Pn=4, thr=15.0, lik=0.3, min_cams=2,
                  undistort=False, lr_swap=False, seed=3, assoc=True),
+    # single-person association: the person of interest among 3 detections per camera
+    'single': dict(workload='8 cams x 3 detections per camera x 50k frames, single-person association on the Neck keypoint (Demo_SinglePerson mode)',
+                   F=50_000, C=8, model='HALPE_26', Pn=3, thr=20.0, lik=0.3, min_cams=2,
+                   undistort=False, lr_swap=False, seed=6, single=True,
+                   gen=dict(p_lowlik=0.02, p_outlier=0.02, p_missing_cam=0.0)),
     # per-GPU shard of BASELINE configs[3] (1M frames over 8 GPUs)
     'cfg4': dict(workload='synthetic 16-cam x COCO_133 (131 kpts) x 125k frames/GPU, min_cameras=3 (BASELINE configs[3] shard)',
                  F=125_000, C=16, model='COCO_133', Pn=1, thr=15.0, lik=0.3, min_cams=3,
@@ -156,6 +161,82 @@ def bench_association(args, cfg, rank, world, local_rank):
     print(json.dumps(out), flush=True)
 
 
+def bench_single(args, cfg, rank, world, local_rank):
+    """Single-person association: every frame searches the 3^8 person combinations in the reference's order."""
+    import torch
+    import torch.distributed as dist
+    from pose2sim_amd import skeletons
+    from pose2sim_amd.engine import Engine, P2S_F32
+    xyl, cams, P, swap, K = make_workload(cfg, rank)
+    n_persons, kpts = make_association_inputs(xyl, cfg['seed'] + rank)
+    ids, names, _ = skeletons.keypoints(cfg['model'])
+    kid = names.index('Neck')                              # column of the tracked keypoint in the packed array
+    tracked = np.ascontiguousarray(kpts[:, kid, :])
+    F, C = n_persons.shape
+    offsets = np.zeros(F + 1, dtype=np.int64)
+    np.cumsum(n_persons.sum(axis=1, dtype=np.int64), out=offsets[1:])
+    dev = torch.device('cuda', local_rank)
+    eng = Engine(local_rank)
+    eng.set_calibration(P, cams)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_np = torch.from_numpy(n_persons).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    d_tk = torch.from_numpy(tracked).to(dev)
+    d_comb = torch.empty((F, C), dtype=torch.int32, device=dev)
+    d_err = torch.empty((F,), dtype=torch.float64, device=dev)
+    d_Q = torch.empty((F, 3), dtype=torch.float64, device=dev)
+
+    def step():
+        eng.associate_single_device(F, P2S_F32, d_np, d_off, d_tk, cfg['thr'], cfg['lik'], cfg['min_cams'], d_comb, d_err, d_Q)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    found = int(torch.isfinite(d_err).sum().item())
+    out = {'metric': 'association-frames/sec', 'value': F * world * args.steps / dt, 'unit': 'frames/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': cfg['workload'], 'frames_per_gpu': F, 'cams': C,
+                      'combinations_per_frame_max': int(np.prod(np.maximum(n_persons, 1).astype(np.float64), axis=1).max()),
+                      'frames_with_a_solution': found, 'parallelism': f'frame shards x{world}'},
+           'roofline': {'bound': 'mfma', 'achieved': None, 'peak': None, 'unit': 'TFLOP/s', 'frac': None, 'traffic': None,
+                        'note': 'fp64-VALU-bound search on 24 B per detection; HBM and MFMA fractions are not meaningful'}}
+    if not args.no_cpu_baseline:
+        from oracle import association_single_ref as sr
+        nfr = args.cpu_frames or 10
+        t0 = time.perf_counter()
+        row = 0
+        for f in range(nfr):
+            per_cam = []
+            for c in range(C):
+                per_cam.append([list(tracked[row + i].astype(np.float64)) for i in range(n_persons[f, c])])
+                row += n_persons[f, c]
+            sr.best_persons_and_cameras(per_cam, sr.persons_combinations(n_persons[f]), [np.asarray(p) for p in P], 0,
+                                        cfg['thr'], cfg['min_cams'], cfg['lik'])
+        cdt = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': nfr / cdt, 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+                               'sample': f'first {nfr} frames of the same workload ({cdt:.1f} s), NumPy oracle'}
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
+
+
 def cpu_baseline(cfg, xyl, cams, P, swap, budget_frames):
     """The CPU oracle (a loop-faithful NumPy port of the reference) on the first frames."""
     from oracle import triangulation_ref as tr
@@ -210,8 +291,8 @@ def main():
     from pose2sim_amd.engine import Engine, P2S_F32
 
     cfg = CONFIGS[args.config]
-    if cfg.get('assoc'):
-        bench_association(args, cfg, rank, world, local_rank)
+    if cfg.get('assoc') or cfg.get('single'):
+        (bench_single if cfg.get('single') else bench_association)(args, cfg, rank, world, local_rank)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -340,7 +421,7 @@ def main():
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
+                         'kernel': ('p2s_tri_level0_direct_kernel' if C <= 8 else 'p2s_tri_level0_kernel') + ' + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }
         if not args.no_cpu_baseline and world == 1:

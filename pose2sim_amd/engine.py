@@ -184,6 +184,15 @@ class Engine:
                                                        _ptr(comb), _ptr(err), _ptr(Q)))
         return comb, err, Q
 
+    def associate_single_device(self, F, dtype, d_n_persons, d_offsets, d_tracked, reproj_thr, lik_thr, min_cams,
+                                d_comb, d_err, d_Q):
+        """Device-pointer form of associate_single; the caller has checked persons per camera <= 16 and the
+        number of combinations per frame (the host entry point does both)."""
+        prm = SingleParams(float(reproj_thr), float(lik_thr), int(min_cams), 0)
+        _lib.check(self._lib.p2s_associate_single_device(self._h, int(F), int(dtype), _ptr(d_n_persons), _ptr(d_offsets),
+                                                         _ptr(d_tracked), C.byref(prm), _ptr(d_comb), _ptr(d_err),
+                                                         _ptr(d_Q)))
+
     def associate_device(self, F, Kj, n_max, dtype, d_n_persons, d_offsets, d_kpts, params, d_aff):
         _lib.check(self._lib.p2s_associate_device(self._h, int(F), int(Kj), int(n_max), int(dtype),
                                                   _ptr(d_n_persons), _ptr(d_offsets), _ptr(d_kpts),

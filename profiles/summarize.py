@@ -1,0 +1,68 @@
+"""Turn the raw rocprofv3 output of profiles/collect.sh (gpurun_out/<round>/) into the small files kept
+under profiles/<round>/ and refresh profiles/traffic.json (what bench.py reports as roofline.traffic)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'gpurun_out', R)
+DST = os.path.join(ROOT, 'profiles', R)
+os.makedirs(DST, exist_ok=True)
+
+
+def short(name):
+    name = name.split('(')[0]
+    name = name.split('<')[0]
+    return name.replace('void ', '').strip()
+
+
+def counter_avg(subdir, counter):
+    """kernel -> average counter value per dispatch (values of one dispatch are summed over its rows)."""
+    per = {}
+    for path in glob.glob(os.path.join(SRC, subdir, '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row['Counter_Name'] != counter:
+                    continue
+                key = (short(row['Kernel_Name']), row['Dispatch_Id'])
+                per[key] = per.get(key, 0.0) + float(row['Counter_Value'])
+    out = {}
+    for (k, _), v in per.items():
+        out.setdefault(k, []).append(v)
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+for f in glob.glob(os.path.join(SRC, 'bench_*.json')):
+    shutil.copy(f, DST)
+stats = glob.glob(os.path.join(SRC, 'trace', '**', '*kernel_stats.csv'), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(DST, 'kernel_stats_cfg2.csv'))
+
+fetch, nf = counter_avg('pmc_fetch', 'FETCH_SIZE')
+write, _ = counter_avg('pmc_write', 'WRITE_SIZE')
+rows, total = [], 0.0
+for k in sorted(fetch):
+    if not k.startswith('p2s_'):
+        continue
+    rd = 2.0 * fetch[k] * 1024.0              # FETCH_SIZE is in KB and counts 128-B requests as 64 B on gfx950
+    wr = write.get(k, 0.0) * 1024.0
+    rows.append((k, nf[k], fetch[k], write.get(k, 0.0), rd, wr, rd + wr))
+with open(os.path.join(DST, 'pmc_hbm_traffic_cfg2.csv'), 'w') as fh:
+    fh.write('kernel,dispatches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_read_bytes(2x FETCH, gfx950 correction),hbm_write_bytes,total_bytes_per_launch\n')
+    for r in rows:
+        fh.write('%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f\n' % r)
+        print(r)
+tri = [r for r in rows if r[0].startswith('p2s_tri_')]
+if tri:
+    # cfg2 is one chunk: one launch of each kernel per step
+    total = sum(r[6] for r in tri)
+    with open(os.path.join(ROOT, 'profiles', 'traffic.json'), 'w') as fh:
+        json.dump({'cfg2': total,
+                   '_note': 'HBM bytes per step of bench.py --config cfg2 (both kernels, one launch each per step), rocprofv3 '
+                            '--pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM '
+                            f'section); source: profiles/{R}/pmc_hbm_traffic_cfg2.csv (profiles/collect.sh + summarize.py)'}, fh, indent=1)
+    print('traffic per step', total)
