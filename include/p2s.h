@@ -166,6 +166,44 @@ int p2s_timing_end(p2s_ctx *ctx, float *elapsed_ms);
 int p2s_tri_geometry(int32_t n_cams, int32_t n_kpts, int32_t dtype, int32_t *blocks_per_tile,
                      int32_t *threads, int32_t *lds_bytes);
 
+/* ---- OpenPose-JSON ingest (host threads; no GPU involved) ------------------------------------------------
+ * Replaces the reference's per-frame, per-person file parsing -- extract_files_frame_f
+ * (triangulation.py:607-653: json.load of every camera file once PER PERSON), count_persons_in_json
+ * (:77-90) and read_json (personAssociation.py:260-274) -- by one parse of every file into a batch and
+ * gather calls that lay the numbers out for p2s_triangulate_* / p2s_associate_*.  A file counts as
+ * unreadable exactly when Python's open(path, 'r') + json.load would raise (missing, not UTF-8, not JSON
+ * in json.load's dialect: NaN / Infinity literals accepted, control characters in strings rejected,
+ * trailing data rejected); repeated object keys take the last value. */
+typedef struct p2s_json_batch p2s_json_batch;
+
+#define P2S_JSON_UNREADABLE (-1)      /* people count of a file json.load would raise on (or an empty path) */
+#define P2S_JSON_NO_PEOPLE_LIST (-2)  /* valid JSON without a top-level object holding a "people" array      */
+#define P2S_JSON_PERSON_NO_LIST (-1)      /* person length: not an object / no "pose_keypoints_2d" array    */
+#define P2S_JSON_PERSON_NOT_NUMERIC (-2)  /* person length: the array holds strings / arrays / objects      */
+
+/* paths: the file names back to back (no separators needed), path_offsets [n_files+1] byte offsets into it;
+ * an empty name = no file for that slot.  n_threads <= 0: one per hardware thread. */
+int p2s_json_parse(const char *paths, const int64_t *path_offsets, int64_t n_files, int32_t n_threads,
+                   p2s_json_batch **out);
+int p2s_json_free(p2s_json_batch *batch);
+/* counts [n_files]: len(js['people']) or a P2S_JSON_* code; person_base [n_files+1]: prefix sums of
+ * max(count, 0) = row of each file's first person in p2s_json_person_lengths.  Either may be NULL. */
+int p2s_json_people_counts(const p2s_json_batch *batch, int32_t *counts, int64_t *person_base);
+/* lengths [person_base[n_files]]: len(person['pose_keypoints_2d']) or a P2S_JSON_PERSON_* code. */
+int p2s_json_person_lengths(const p2s_json_batch *batch, int32_t *lengths);
+/* extract_files_frame_f for every file at once: for file i and person n < max_persons writes
+ * out[file_offsets[i] + n*person_stride + 3*k + {0,1,2}] = values[3*keypoint_ids[k] + {0,1,2}], NaN when
+ * the file, the person or the triplet does not exist (triangulation.py:629-644); file_offsets[i] < 0 skips
+ * the file.  Offsets and strides are in elements of dtype.  n_inexact (may be NULL) counts the values a
+ * P2S_F32 output could not hold exactly, so that the caller can ask again in P2S_F64. */
+int p2s_json_gather_keypoints(const p2s_json_batch *batch, const int32_t *keypoint_ids, int32_t n_ids,
+                              int32_t max_persons, const int64_t *file_offsets, int64_t person_stride,
+                              int32_t dtype, void *out, int64_t *n_inexact);
+/* read_json layout: row r = the first n_values numbers of person person_index[r] of file file_index[r]
+ * (NaN-padded), out [n_rows][n_values]. */
+int p2s_json_gather_people(const p2s_json_batch *batch, const int64_t *file_index, const int32_t *person_index,
+                           int64_t n_rows, int32_t n_values, int32_t dtype, void *out, int64_t *n_inexact);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ P2S_MAX_CAMS = 32
 P2S_MAX_PERSONS_TOTAL = 48
 P2S_MAX_PERSONS_PER_CAM = 16
 P2S_MAX_COMBINATIONS = 1 << 20
+P2S_JSON_UNREADABLE, P2S_JSON_NO_PEOPLE_LIST = -1, -2
+P2S_JSON_PERSON_NO_LIST, P2S_JSON_PERSON_NOT_NUMERIC = -1, -2
 
 
 class TriParams(C.Structure):
@@ -66,6 +68,14 @@ SIGNATURES = {
                                             C.POINTER(SingleParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     'p2s_timing_begin': (C.c_int, [C.c_void_p]),
     'p2s_timing_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    'p2s_json_parse': (C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    'p2s_json_free': (C.c_int, [C.c_void_p]),
+    'p2s_json_people_counts': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    'p2s_json_person_lengths': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'p2s_json_gather_keypoints': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                            C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]),
+    'p2s_json_gather_people': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.POINTER(C.c_int64)]),
     'p2s_tri_geometry': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32)]),
 }

@@ -149,6 +149,17 @@ int check_tri(p2s_ctx *ctx, int64_t n_blocks, int32_t K, int32_t dtype, const p2
 
 }  // namespace
 
+// Error slot shared with the host-side translation units (p2s_ingest.cpp).
+int p2s_set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
 extern "C" {
 
 int p2s_version(void) { return 100; }

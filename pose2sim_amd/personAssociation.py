@@ -101,14 +101,41 @@ def recap_tracking(config_dict, error=0, nb_cams_excluded=0):
     logging.info(f'\nTracked json files are stored in {os.path.realpath(poseTracked_dir)}.')
 
 
-def count_persons_for_combinations(path):
-    """persons_combinations' own count (personAssociation.py:84-91): people whose x values are not all NaN;
-    0 when the file cannot be read."""
-    try:
-        people = poseio._load(path)['people']
-        return len([p for p in people if not all(np.isnan(p['pose_keypoints_2d'][::3]))])
-    except Exception:
-        return 0
+def single_person_candidates(paths, k3):
+    """Per file: persons_combinations' count (personAssociation.py:84-91: people whose x values are not all
+    NaN; 0 when the file cannot be read or a person has no keypoint list) and, for candidate i < count, the
+    values [k3:k3+3] of read_json's i-th person (people with >= 3 values, :260-274), NaN when there is none.
+    -> (counts int32 [n_files], tracked float64 [sum(counts)][3])."""
+    from .ingest import P2S_JSON_PERSON_NO_LIST, P2S_JSON_PERSON_NOT_NUMERIC, JsonBatch
+    with JsonBatch(paths) as batch:
+        lengths = batch.person_lengths
+        n_files = len(paths)
+        file_of = np.repeat(np.arange(n_files, dtype=np.int64), np.maximum(batch.counts, 0))
+        person_of = (np.arange(len(file_of), dtype=np.int64) - batch.person_base[file_of]).astype(np.int32)
+        broken = np.zeros(n_files, dtype=bool)
+        broken[file_of[(lengths == P2S_JSON_PERSON_NO_LIST) | (lengths == P2S_JSON_PERSON_NOT_NUMERIC)]] = True
+        width = int(max(lengths.max(initial=0), k3 + 3))
+        vals, _ = batch.gather_people(file_of, person_of, width, np.float64)
+        xs = vals[:, 0::3]
+        in_list = np.arange(xs.shape[1])[None, :] * 3 < np.maximum(lengths, 0)[:, None]
+        all_nan = (np.isnan(xs) | ~in_list).all(axis=1)                       # all([]) is True: empty lists drop out
+        counted = ~all_nan & ~broken[file_of]
+        counts = np.bincount(file_of[counted], minlength=n_files).astype(np.int32)
+        listed = (lengths >= 3) & ~broken[file_of]                           # read_json's list
+        n_listed = np.bincount(file_of[listed], minlength=n_files)
+        first = np.zeros(n_files + 1, dtype=np.int64)
+        np.cumsum(n_listed, out=first[1:])
+        listed_rows = np.flatnonzero(listed)
+        cand_file = np.repeat(np.arange(n_files, dtype=np.int64), counts)
+        cand_base = np.zeros(n_files + 1, dtype=np.int64)
+        np.cumsum(counts, out=cand_base[1:])
+        cand_j = np.arange(len(cand_file), dtype=np.int64) - cand_base[cand_file]
+        tracked = np.full((len(cand_file), 3), np.nan)
+        has = cand_j < n_listed[cand_file]
+        src = listed_rows[(first[cand_file] + cand_j)[has]]
+        ok = lengths[src] >= k3 + 3
+        tracked[np.flatnonzero(has)[ok]] = vals[src[ok], k3:k3 + 3]
+    return counts, tracked
 
 
 def _associate_single_person(config_dict, frames_src, frames_dst, n_cams, P_all, calib_params):
@@ -131,18 +158,11 @@ def _associate_single_person(config_dict, frames_src, frames_dst, n_cams, P_all,
         logging.warning(f'{tracked_keypoint} not found in {pose_model}, consider editing tracked_keypoint in Config.toml. Tracking {tracked_keypoint_name} instead.')
     k3 = tracked_keypoint_id * 3
 
-    # the tracked keypoint of every candidate person: index i of a camera is read_json's i-th person (:200-202)
+    # the tracked keypoint of every candidate person: index i of a camera is read_json's i-th person (:200-202),
+    # the number of candidates is persons_combinations' own count (:84-91); one native parse of every file
     F = len(frames_src)
-    n_persons = np.zeros((F, n_cams), dtype=np.int32)
-    tracked = []
-    for fi, src in enumerate(frames_src):
-        for c in range(n_cams):
-            n = count_persons_for_combinations(src[c])
-            people = poseio.read_people(src[c]) if n else []
-            n_persons[fi, c] = n
-            for i in range(n):
-                v = list(people[i][k3:k3 + 3]) if i < len(people) else []
-                tracked.append(v if len(v) == 3 else [np.nan, np.nan, np.nan])
+    n_persons, tracked = single_person_candidates([p for src in frames_src for p in src], k3)
+    n_persons = n_persons.reshape(F, n_cams)
     if n_persons.max(initial=0) > P2S_MAX_PERSONS_PER_CAM:
         raise ValueError(f'a camera holds more than {P2S_MAX_PERSONS_PER_CAM} detections in one frame')
     if np.prod(np.maximum(n_persons, 1).astype(np.float64), axis=1).max(initial=0) > P2S_MAX_COMBINATIONS:
@@ -233,28 +253,17 @@ def associate_all(config_dict):
     logging.info('\nMulti-person analysis selected.')
 
     # ---- read every frame (always from pose/: the reference's os.path.exist typo at :764) --------
-    src_files, dst_files, people_all = [], [], []
-    n_persons = np.zeros((len(frames), n_cams), dtype=np.int32)
-    Kj3 = None
-    for fi, f in enumerate(frames):
+    src_files, dst_files = [], []
+    for f in frames:
         names = [maps[c].get(f, 'none') for c in range(n_cams)]
-        src = [os.path.join(pose_dir, json_dirs_names[c], names[c]) for c in range(n_cams)]
-        dst = [os.path.join(poseTracked_dir, json_dirs_names[c], names[c]) for c in range(n_cams)]
-        src_files.append(src)
-        dst_files.append(dst)
-        for c in range(n_cams):
-            people = poseio.read_people(src[c])
-            n_persons[fi, c] = len(people)
-            for p in people:
-                if Kj3 is None:
-                    Kj3 = len(p)
-                if len(p) != Kj3 or Kj3 % 3:
-                    raise ValueError(f'{src[c]}: every person must carry the same number of keypoint triplets')
-                people_all.append(p)
+        src_files.append([os.path.join(pose_dir, json_dirs_names[c], names[c]) for c in range(n_cams)])
+        dst_files.append([os.path.join(poseTracked_dir, json_dirs_names[c], names[c]) for c in range(n_cams)])
+    n_people, rows, Kj3 = poseio.read_people_batch([p for src in src_files for p in src])     # one native parse
+    n_persons = n_people.reshape(len(frames), n_cams)
     if n_persons.sum(axis=1).max(initial=0) > P2S_MAX_PERSONS_TOTAL:
         raise ValueError(f'a frame holds more than {P2S_MAX_PERSONS_TOTAL} detections over all cameras')
     Kj = (Kj3 or 3) // 3
-    kpts = np.asarray(people_all, dtype=np.float64).reshape(-1, Kj, 3)
+    kpts = rows.reshape(-1, Kj, 3)
 
     # ---- rays, affinity and matchSVT of every frame: one call into the HIP engine ------------------
     engine = _make_engine()

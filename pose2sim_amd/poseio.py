@@ -72,50 +72,96 @@ def count_persons(path):
     return len(_load(path).get('people', []))
 
 
-def load_observations(root, json_dirs, maps, f_range, keypoints_ids, nb_persons):
-    """extract_files_frame_f (triangulation.py:607-653) for every frame of f_range at once.
+def _trial_paths(root, json_dirs, json_files_names):
+    paths, index = [], {}
+    for c, d in enumerate(json_dirs):
+        for name in json_files_names[c]:
+            index[(c, name)] = len(paths)
+            paths.append(os.path.join(root, d, name))
+    return paths, index
 
-    Returns float64 [F][nb_persons][C][K][3] with NaN where the reference would append NaN:
-    missing / unreadable file, person index beyond the list, keypoint index beyond the list.
+
+def max_persons_in_trial(batch, paths):
+    """max over all files of count_persons_in_json (triangulation.py:77-90, :784); a file json.load cannot
+    read, or whose 'people' is not a list, goes through the Python function so that the same exception
+    (or len() of whatever 'people' is) comes out."""
+    best = 0
+    for i in np.flatnonzero(batch.counts < 0):
+        best = max(best, count_persons(paths[i]))
+    return max(best, int(batch.counts.max(initial=0)))
+
+
+def load_observations(root, json_dirs, maps, f_range, keypoints_ids, nb_persons, json_files_names=None,
+                      count_all_persons=False):
+    """extract_files_frame_f (triangulation.py:607-653) for every frame of f_range at once, through the native
+    parser (csrc/p2s_ingest.cpp): every file is read and parsed once, on host threads.
+
+    Returns [F][nb_persons][C][K][3] -- float32 when every value is float32-representable (RTMLib output is,
+    poseEstimation.py:259), else float64 -- with NaN where the reference would append NaN: missing /
+    unreadable file, person index beyond the list, keypoint triplet beyond the list.
+    count_all_persons: nb_persons is ignored and taken as the maximum people count over ALL files of
+    json_files_names (multi-person mode, :784); returned second.
     """
+    from .ingest import JsonBatch
     f0, f1 = f_range
     F = max(0, f1 - f0)
     C = len(json_dirs)
     K = len(keypoints_ids)
-    ids = np.asarray(keypoints_ids, dtype=np.int64)
-    out = np.full((F, nb_persons, C, K, 3), np.nan, dtype=np.float64)
+    if count_all_persons:
+        paths, index = _trial_paths(root, json_dirs, json_files_names)
+    else:
+        paths, index = [], {}
+    slot_of = np.full(F * C, -1, dtype=np.int64)            # (frame, camera) -> parsed file
     for c in range(C):
         m = maps[c]
         for fi, f in enumerate(range(f0, f1)):
             name = m.get(f)
             if name is None:
                 continue
-            try:
-                people = _load(os.path.join(root, json_dirs[c], name))['people']
-            except Exception:
-                continue
-            for n in range(min(nb_persons, len(people))):
-                try:
-                    kp = people[n]['pose_keypoints_2d']
-                except Exception:
-                    continue
-                try:
-                    arr = np.asarray(kp, dtype=np.float64)
-                except Exception:
-                    continue
-                L = arr.shape[0] if arr.ndim == 1 else 0
-                # keypoint id*3+2 must exist for the whole triplet to be read (per-keypoint try/except)
-                okk = ids * 3 + 2 < L
-                if okk.all():
-                    out[fi, n, c, :, 0] = arr[ids * 3]
-                    out[fi, n, c, :, 1] = arr[ids * 3 + 1]
-                    out[fi, n, c, :, 2] = arr[ids * 3 + 2]
-                else:
-                    sel = np.flatnonzero(okk)
-                    out[fi, n, c, sel, 0] = arr[ids[sel] * 3]
-                    out[fi, n, c, sel, 1] = arr[ids[sel] * 3 + 1]
-                    out[fi, n, c, sel, 2] = arr[ids[sel] * 3 + 2]
-    return out
+            i = index.get((c, name))
+            if i is None:
+                i = len(paths)
+                index[(c, name)] = i
+                paths.append(os.path.join(root, json_dirs[c], name))
+            slot_of[fi * C + c] = i
+    with JsonBatch(paths) as batch:
+        if count_all_persons:
+            nb_persons = max_persons_in_trial(batch, paths)
+        file_offsets = np.full(len(paths), -1, dtype=np.int64)
+        used = np.flatnonzero(slot_of >= 0)
+        fi, c = used // C, used % C
+        file_offsets[slot_of[used]] = (fi * nb_persons * C + c) * (K * 3)
+        out = np.full((F, nb_persons, C, K, 3), np.nan, dtype=np.float32)
+        if out.size and batch.gather_keypoints(keypoints_ids, nb_persons, file_offsets, C * K * 3, out):
+            out = np.full((F, nb_persons, C, K, 3), np.nan, dtype=np.float64)
+            batch.gather_keypoints(keypoints_ids, nb_persons, file_offsets, C * K * 3, out)
+    return (out, nb_persons) if count_all_persons else out
+
+
+def read_people_batch(paths):
+    """read_json (personAssociation.py:260-274) for many files at once.
+    -> (n_people [n_files], rows float [sum][Kj3], Kj3): people with >= 3 values in JSON order; a file that
+    cannot be read, has no 'people' list, or holds a person without a 'pose_keypoints_2d' list gives none."""
+    from .ingest import P2S_JSON_PERSON_NO_LIST, P2S_JSON_PERSON_NOT_NUMERIC, JsonBatch
+    with JsonBatch(paths) as batch:
+        lengths = batch.person_lengths
+        n_files = len(paths)
+        file_of = np.repeat(np.arange(n_files, dtype=np.int64), np.maximum(batch.counts, 0))
+        person_of = (np.arange(len(file_of), dtype=np.int64) - batch.person_base[file_of]).astype(np.int32)
+        broken = np.zeros(n_files, dtype=bool)
+        broken[file_of[lengths == P2S_JSON_PERSON_NO_LIST]] = True                 # js[...]['pose_keypoints_2d'] raises
+        if (lengths == P2S_JSON_PERSON_NOT_NUMERIC).any():
+            bad = paths[int(file_of[np.flatnonzero(lengths == P2S_JSON_PERSON_NOT_NUMERIC)[0]])]
+            raise ValueError(f'{bad}: pose_keypoints_2d must hold numbers only')
+        keep = (lengths >= 3) & ~broken[file_of]
+        n_people = np.bincount(file_of[keep], minlength=n_files).astype(np.int32)
+        kept_len = lengths[keep]
+        Kj3 = int(kept_len[0]) if kept_len.size else 0
+        if kept_len.size and ((kept_len != Kj3).any() or Kj3 % 3):
+            i = int(np.flatnonzero(keep)[np.flatnonzero((kept_len != Kj3) | bool(Kj3 % 3))[0]])
+            raise ValueError(f'{paths[int(file_of[i])]}: every person must carry the same number of keypoint triplets')
+        rows, _ = batch.gather_people(file_of[keep], person_of[keep], Kj3, np.float64)
+    return n_people, rows, Kj3
 
 
 def read_people(path):

@@ -147,15 +147,14 @@ def triangulate_all(config_dict):
     if n_cams != len(P):
         raise Exception(f'Error: The number of cameras is not consistent: Found {len(P)} cameras in the calibration file, and {n_cams} cameras based on the number of pose folders.')
 
+    # ---- every frame at once: JSON -> packed tensor (native parser) -> HIP engine -------------------
+    maps = poseio.frame_file_map(json_files_names)
     if multi_person:
-        nb_persons = max(max(poseio.count_persons(os.path.join(pose_dir, json_dirs_names[c], name))
-                             for name in json_files_names[c]) for c in range(n_cams))
+        xyl, nb_persons = poseio.load_observations(pose_dir, json_dirs_names, maps, f_range, keypoints_ids, 0,
+                                                   json_files_names=json_files_names, count_all_persons=True)
     else:
         nb_persons = 1
-
-    # ---- every frame at once: JSON -> packed tensor -> HIP engine ----------------------------
-    maps = poseio.frame_file_map(json_files_names)
-    xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, f_range, keypoints_ids, nb_persons)
+        xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, f_range, keypoints_ids, nb_persons)
     engine = _make_engine()
     engine.set_calibration(P, calib_params if undistort_points else None)
     prm = engine.tri_params(error_threshold, likelihood_threshold, min_cameras, undistort_points, handle_LR_swap)
