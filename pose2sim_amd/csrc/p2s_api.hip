@@ -329,9 +329,11 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     // search kernel geometry: LDS = [P][binom][waves x 64 records]
     const int lds_binom_off = (C * 12 * 8 + 15) / 16 * 16;
     const int lds_rec_off = (lds_binom_off + 33 * 33 * 4 + 15) / 16 * 16;
-    const int64_t fit = (40 * 1024) / (64 * (int64_t)(rec_bytes + 96));
+    int job = 40;                                      // records per search job (32..48 measure alike on cfg2)
+    if (const char *j = getenv("P2S_JOB")) job = std::max(8, std::min(64, atoi(j)));   // kernel experiments only
+    const int64_t fit = (40 * 1024) / (job * (int64_t)(rec_bytes + 96));
     const int wpb = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;   // waves per search workgroup
-    const int lds1 = lds_rec_off + wpb * 64 * (rec_bytes + 96);   // per wave: 64 records + 64 owner states
+    const int lds1 = lds_rec_off + wpb * job * (rec_bytes + 96);  // per wave: `job` records + `job` owner states
     if (lds1 > 160 * 1024) return fail(P2S_ERR_INVALID_ARG, "search records of C=%d do not fit in LDS", C);
 
     P2sTriArgs a{};
@@ -344,6 +346,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     a.rec_bytes = rec_bytes;
     a.wl_capacity = (uint32_t)shard_cap;
     a.lds_binom_off = lds_binom_off; a.lds_rec_off = lds_rec_off;
+    a.job = job;
     a.min_cams = params->min_cameras;
     a.undistort = params->undistort_points ? 1 : 0;
     a.lr_swap = params->handle_lr_swap ? 1 : 0;
@@ -362,7 +365,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         L.lds0 = g.lds_bytes;
         // persistent search grid: what stays resident at 3 waves per SIMD (256 CUs x 12 waves), no
         // more than the chunk could ever need
-        const int64_t need_waves = (a.n_blocks * n_kpts + 31) / 32;
+        const int64_t need_waves = (a.n_blocks * n_kpts + job - 1) / job;
         const int64_t waves = std::max<int64_t>(wpb, std::min<int64_t>(3072, need_waves));
         L.grid1 = (int)((waves + wpb - 1) / wpb);
         L.threads1 = 64 * wpb;

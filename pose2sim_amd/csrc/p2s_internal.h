@@ -41,6 +41,7 @@ struct P2sTriArgs {
     int32_t K, C, FB;
     int32_t lds_binom_off, lds_rec_off;   // kernel 2 LDS layout: [P][binom][records]
     int32_t min_cams, undistort, lr_swap;
+    int32_t job;                 // work-list records a search wave takes at a time (<= 64); sizes its LDS region
     int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
     double thr, lik_thr;
 };

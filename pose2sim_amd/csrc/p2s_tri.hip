@@ -34,7 +34,6 @@ constexpr double kInf = __builtin_huge_val();
 // every uniform-index access become a scalar (SMEM) load and the value an SGPR operand.
 typedef const __attribute__((address_space(4))) P2sCam *cam_cptr;
 
-constexpr int P2S_JOB = 32;   // work-list records a search wave takes at a time (<= 64)
 
 __device__ __forceinline__ double d_nan() { return __builtin_nan(""); }
 
@@ -802,16 +801,16 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int waves_per_block = blockDim.x >> 6;
-    // per wave: 64 records, then 64 owner states {N[10] f64, nanmask u32, zeromask u32, pad} of 96 bytes
-    unsigned char *recs = smem + a.lds_rec_off + (size_t)wave * 64 * (a.rec_bytes + 96);
-    unsigned char *states = recs + (size_t)64 * a.rec_bytes;
+    // per wave: a.job records, then a.job owner states {N[10] f64, nanmask u32, zeromask u32, pad} of 96 bytes
+    unsigned char *recs = smem + a.lds_rec_off + (size_t)wave * a.job * (a.rec_bytes + 96);
+    unsigned char *states = recs + (size_t)a.job * a.rec_bytes;
 
     for (int i = tid; i < C * 12; i += blockDim.x) sP[i] = a.cams[i / 12].P[i % 12];
     for (int i = tid; i < 33 * 33; i += blockDim.x) sBinom[i] = a.binom[i];
     __syncthreads();
 
     // Wave w serves shard w % SHARDS (shards fill evenly: every SHARDS-th tile); the waves of a shard
-    // pull jobs of P2S_JOB records through the shard's atomic ticket until it is drained.
+    // pull jobs of a.job records through the shard's atomic ticket until it is drained.
     const uint32_t gwave = blockIdx.x * waves_per_block + wave;
     const double thr = a.thr;
     const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
@@ -819,13 +818,24 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
     uint32_t *ticket = a.wl_count + P2S_WL_SHARDS + shard;
     const uint32_t count = min(a.wl_count[shard], a.wl_capacity);
 
+    // diagnostics (debug_mode 5, exp/k2_trace.py): per-wave timeline instead of results.  What it showed on
+    // cfg2: all waves start within 1 us, the first ends at 0.65 and the median at 0.78 of the kernel (the
+    // oldest wave of a SIMD has issue priority, so a shard's last jobs run on its slowest waves); guided job
+    // sizes or stealing across shards need a device-scope look at the tickets first, which costs more
+    // (~4 us per job) than the tail they remove.
+    const bool trace = a.debug_mode == 5;
+    uint64_t t_begin = 0, t_fetch = 0, t_n = 0, t_lvl1 = 0, t_search = 0;
+    uint32_t n_jobs = 0;
+    if (trace) t_begin = __builtin_amdgcn_s_memrealtime();
     for (;;) {
+        uint64_t t0 = 0;
+        if (trace) t0 = __builtin_amdgcn_s_memtime();
         uint32_t job = 0;
         if (lane == 0) job = atomicAdd(ticket, 1u);
         job = __shfl(job, 0, 64);
-        const uint32_t rec0 = job * P2S_JOB;
+        const uint32_t rec0 = job * (uint32_t)a.job;
         if (rec0 >= count) break;                                  // shard drained
-        const int n = (int)min((uint32_t)P2S_JOB, count - rec0);
+        const int n = (int)min((uint32_t)a.job, count - rec0);
         // ---- this wave's records: contiguous copy into its LDS region ----------------------
         {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(a.wl_rec + ((size_t)shard * a.wl_capacity + rec0) * a.rec_bytes);
@@ -837,6 +847,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        if (trace) { __builtin_amdgcn_sched_barrier(0); t_fetch += __builtin_amdgcn_s_memtime() - t0; ++n_jobs; t0 = __builtin_amdgcn_s_memtime(); }
         const bool active = lane < n;
         const unsigned char *myrec = recs + (size_t)(active ? lane : 0) * a.rec_bytes;
         const uint32_t u = *reinterpret_cast<const uint32_t *>(myrec);          // unit id within the chunk
@@ -850,7 +861,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         classify_and_accumulate<T, 0>(cams, C, obs, N, nanmask, zeromask);
         const int V = __popc(nanmask | zeromask);
         const int Lmax = active ? C - a.min_cams - V : -1;
-        {   // publish the owner state: the lanes of the group that works on this unit read it from LDS
+        if (lane < a.job) {   // publish the owner state: the lanes of the group that works on this unit read it from LDS
             double *sN = reinterpret_cast<double *>(states + (size_t)lane * 96);
 #pragma unroll
             for (int i = 0; i < 10; ++i) sN[i] = N[i];
@@ -865,10 +876,12 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         double Qb[3] = {d_nan(), d_nan(), d_nan()};
         int n_excl = C;
         uint32_t mask = allmask;
+        if (trace) { __builtin_amdgcn_sched_barrier(0); t_n += __builtin_amdgcn_s_memtime() - t0; t0 = __builtin_amdgcn_s_memtime(); }
 
         // ---- subset search, levels in lock step across the wave -----------------------------
         unsigned long long pend_level = __ballot(Lmax >= 1);
         for (int level = 1; pend_level != 0ull; ++level) {
+            if (trace && level == 2) { __builtin_amdgcn_sched_barrier(0); t_lvl1 += __builtin_amdgcn_s_memtime() - t0; }
             unsigned long long pending = pend_level;
             bool cont = false;                                      // owner lanes: continue to level+1
             const uint32_t nsub = sBinom[C * 33 + level];
@@ -895,7 +908,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 const int owner = nth_set_bit(batch, grp);            // record this group works on (lane id) or -1
 
                 // the owner's state
-                const int src = owner < 0 ? lane : owner;
+                const int src = owner < 0 ? 0 : owner;
                 const double *oN = reinterpret_cast<const double *>(states + (size_t)src * 96);
                 const uint32_t o_nan = reinterpret_cast<const uint32_t *>(oN + 10)[0];
                 const uint32_t o_zero = reinterpret_cast<const uint32_t *>(oN + 10)[1];
@@ -994,8 +1007,9 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
             pend_level = __ballot(cont);
         }
 
+        if (trace) { __builtin_amdgcn_sched_barrier(0); t_search += __builtin_amdgcn_s_memtime() - t0; }
         // ---- finalise (triangulation.py:588-604) ------------------------------------------
-        if (active) {
+        if (active && !trace) {
             const int64_t gu = a.block0 * a.K + u;
             const bool fail = !(err_min <= thr);
             double *Qo = a.Q + gu * 3;
@@ -1008,6 +1022,11 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next records overwrite this wave's LDS region
         __builtin_amdgcn_wave_barrier();
+    }
+    if (trace && lane == 0) {
+        double *o = a.Q + (size_t)gwave * 8;
+        o[0] = (double)t_begin; o[1] = (double)__builtin_amdgcn_s_memrealtime(); o[2] = (double)n_jobs;
+        o[3] = (double)t_fetch; o[4] = (double)t_n; o[5] = (double)t_lvl1; o[6] = (double)t_search; o[7] = 0.0;
     }
 }
 
