@@ -44,6 +44,31 @@ def rodrigues_inv(R):
     return theta * w / (2.0 * np.sin(theta))
 
 
+def rodrigues_from_matrix(R):
+    """Rotation matrix -> rotation vector, cv2.Rodrigues' matrix branch restated from OpenCV's published
+    algorithm: re-orthonormalise through the SVD, theta = acos((tr - 1) / 2), axis from the antisymmetric part
+    (from the diagonal when sin(theta) < 1e-5).  Returns shape (3,)."""
+    R = np.asarray(R, dtype=np.float64).reshape(3, 3)
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    rx, ry, rz = R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]
+    s = np.sqrt((rx * rx + ry * ry + rz * rz) * 0.25)
+    c = min(max((R[0, 0] + R[1, 1] + R[2, 2] - 1.0) * 0.5, -1.0), 1.0)
+    theta = np.arccos(c)
+    if s < 1e-5:
+        if c > 0:
+            return np.zeros(3)
+        rx = np.sqrt(max((R[0, 0] + 1.0) * 0.5, 0.0))
+        ry = np.sqrt(max((R[1, 1] + 1.0) * 0.5, 0.0)) * (-1.0 if R[0, 1] < 0 else 1.0)
+        rz = np.sqrt(max((R[2, 2] + 1.0) * 0.5, 0.0)) * (-1.0 if R[0, 2] < 0 else 1.0)
+        if abs(rx) < abs(ry) and abs(rx) < abs(rz) and ((R[1, 2] > 0) != (ry * rz > 0)):
+            rz = -rz
+        theta /= np.sqrt(rx * rx + ry * ry + rz * rz)
+        return np.array([rx, ry, rz]) * theta
+    vth = theta / (2.0 * s)
+    return np.array([rx, ry, rz]) * vth
+
+
 def _dist12(dist):
     """Pad an OpenCV distortion vector (4, 5, 8, 12 or 14 terms) to the 12 terms used below."""
     d = np.zeros(12, dtype=np.float64)

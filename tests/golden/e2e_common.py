@@ -36,7 +36,8 @@ def cams_from_arrays(z, prefix=''):
             'T': [z[prefix + 'T'][c] for c in range(C)], 'names': [f'cam_{c + 1:02d}' for c in range(C)]}
 
 
-def write_trial(root, trial_name, cams, people_per_frame_cam, json_subdir='pose', n_json_kpts=26, model_ids=None):
+def write_trial(root, trial_name, cams, people_per_frame_cam, json_subdir='pose', n_json_kpts=26, model_ids=None,
+                calib_text=None):
     """root/Config.toml (session marker), root/calibration/Calib.toml,
     root/<trial>/<json_subdir>/cam_XX_json/cam_XX_%06d.json.
 
@@ -46,9 +47,14 @@ def write_trial(root, trial_name, cams, people_per_frame_cam, json_subdir='pose'
     os.makedirs(root, exist_ok=True)
     open(os.path.join(root, 'Config.toml'), 'a').close()
     os.makedirs(os.path.join(root, 'calibration'), exist_ok=True)
-    calib_mod.write_calibration_toml(os.path.join(root, 'calibration', 'Calib.toml'), cams)
+    if calib_text is not None:                       # a calibration file given as text (cams is ignored)
+        with open(os.path.join(root, 'calibration', 'Calib.toml'), 'w') as fh:
+            fh.write(calib_text)
+        C = len(people_per_frame_cam[0])
+    else:
+        calib_mod.write_calibration_toml(os.path.join(root, 'calibration', 'Calib.toml'), cams)
+        C = len(cams['K'])
     trial = os.path.join(root, trial_name)
-    C = len(cams['K'])
     for sub in {'pose', json_subdir}:
         for c in range(C):
             os.makedirs(os.path.join(trial, sub, f'cam_{c + 1:02d}_json'), exist_ok=True)

@@ -89,7 +89,10 @@ def _cv2_module():
         return S.reshape(-1, 1), U, Vt
 
     def Rodrigues(r):
-        return cvmath.rodrigues(np.asarray(r, dtype=np.float64)), None
+        r = np.asarray(r, dtype=np.float64)
+        if r.size == 9:                                  # matrix -> vector (calibration converters)
+            return cvmath.rodrigues_from_matrix(r).reshape(3, 1), None
+        return cvmath.rodrigues(r), None
 
     def getOptimalNewCameraMatrix(K, dist, size, alpha, new_size=None):
         return cvmath.get_optimal_new_camera_matrix(K, dist, size, alpha, new_size), (0, 0, 0, 0)
