@@ -88,6 +88,40 @@ __device__ __forceinline__ void accum_camera(double N[10], PT P, double x, doubl
     N[9] = fma(s3, a3, fma(t3, b3, N[9]));
 }
 
+// One step of iterative refinement for smallest_eigvec (see the end of that function): out of line and with
+// scalar arguments (a pointer argument of a non-inlined function would force the matrix into scratch), so
+// that the rare call leaves the register allocation of the hot loop alone.
+__device__ __noinline__ double3 refine_eigvec(double n00, double m01, double m02, double b0, double n11, double m12,
+                                              double b1, double n22, double b2, double c, double lam, double q0,
+                                              double q1, double q2) {
+    const double m00 = n00 - lam, m11 = n11 - lam, m22 = n22 - lam;
+    const double c00 = fma(m11, m22, -m12 * m12);
+    const double c01 = fma(m02, m12, -m01 * m22);
+    const double c02 = fma(m01, m12, -m02 * m11);
+    const double c11 = fma(m00, m22, -m02 * m02);
+    const double c12 = fma(m01, m02, -m00 * m12);
+    const double c22 = fma(m00, m11, -m01 * m01);
+    const double det = fma(m00, c00, fma(m01, c01, m02 * c02));
+    const double nid = -fast_rcp(det);
+    const double r0 = fma(m00, q0, fma(m01, q1, fma(m02, q2, b0)));     // residual of (M - lambda) q = -b
+    const double r1 = fma(m01, q0, fma(m11, q1, fma(m12, q2, b1)));
+    const double r2 = fma(m02, q0, fma(m12, q1, fma(m22, q2, b2)));
+    double x0 = fma((c00 * r0 + c01 * r1 + c02 * r2), nid, q0);
+    double x1 = fma((c01 * r0 + c11 * r1 + c12 * r2), nid, q1);
+    double x2 = fma((c02 * r0 + c12 * r1 + c22 * r2), nid, q2);
+    const double p0 = -(c00 * x0 + c01 * x1 + c02 * x2) * nid;          // dq/dlambda at the refined point
+    const double p1 = -(c01 * x0 + c11 * x1 + c12 * x2) * nid;
+    const double p2 = -(c02 * x0 + c12 * x1 + c22 * x2) * nid;
+    const double f = c + (b0 * x0 + b1 * x1 + b2 * x2) - lam;
+    const double dl = f * fast_rcp(1.0 + (x0 * x0 + x1 * x1 + x2 * x2));
+    const bool ok = det > 0.0;
+    double3 r;
+    r.x = ok ? fma(dl, p0, x0) : q0;
+    r.y = ok ? fma(dl, p1, x1) : q1;
+    r.z = ok ? fma(dl, p2, x2) : q2;
+    return r;
+}
+
 // Smallest eigenvector of the 4x4 SPD matrix N, dehomogenised: v = (q, 1), N v = lambda v, i.e.
 // q = V[0:3,3]/V[3,3] of the reference's SVD of A (common.py:348-350), N = A^T A.
 //
@@ -106,8 +140,9 @@ __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3])
     double lam = 0.0, lo = 0.0, hi = kInf;
     double q0 = d_nan(), q1 = d_nan(), q2 = d_nan();
     bool done = false;
+    bool weak = false;                      // M has a nearly free direction: the result gets a refinement step
 #pragma unroll 1
-    for (int it = 0; it < 10; ++it) {
+    for (int it = 0; it < 64; ++it) {      // 2-3 passes as a rule; a root next to the pole mu_1 needs the bisection below
         const double m00 = N[0] - lam, m11 = N[4] - lam, m22 = N[7] - lam;
         const double c00 = fma(m11, m22, -m12 * m12);
         const double c01 = fma(m02, m12, -m01 * m22);
@@ -135,7 +170,10 @@ __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3])
         // times |dq/dlambda| gives the error of the corrected q
         const double t = qp * step * step * rq;
         const bool conv = pd && ((t * t * pp <= 1e-21 * qq) || (fabs(step) <= tol_abs));
-        if (!done && pd) { q0 = fma(step, p0, y0); q1 = fma(step, p1, y1); q2 = fma(step, p2, y2); }
+        if (!done && pd) {
+            q0 = fma(step, p0, y0); q1 = fma(step, p1, y1); q2 = fma(step, p2, y2);
+            weak = pp * 1e6 > qq - 1.0;     // |dq/dlambda| / |q| = 1 / (mu_1 - lambda) above 1e-3
+        }
         double lam_new = lam + step;
         lo = (pd && f >= 0.0) ? lam : lo;
         hi = pd ? hi : fmin(hi, lam);
@@ -146,6 +184,17 @@ __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3])
         if (!done) lam = lam_new;
         done = done || conv || bad;
         if (__all(done)) break;
+    }
+    // With a nearly free direction in M (two cameras facing each other: depth along their common line) the
+    // rounding noise of f(lambda) -- b.q cancels against c to ~1e-10 relative -- leaves lambda off by ~1e-7 and
+    // q off by |dq/dlambda| times that, up to ~1e-7 m.  One step of iterative refinement of (M - lambda) q = -b
+    // with the residual formed in the original data, then lambda and q corrected together, brings it back to
+    // ~1e-11 (checked against the SVD of A on 5.2 M units with 4 ring cameras).  Rare: a whole-wave branch.
+    weak = weak && (q0 == q0);
+    if (__any(weak)) {
+        const double3 x = refine_eigvec(N[0], N[1], N[2], N[3], N[4], N[5], N[6], N[7], N[8], N[9], lam, q0, q1, q2);
+        const bool use = weak && (x.x == x.x) && (x.y == x.y) && (x.z == x.z);
+        q0 = use ? x.x : q0; q1 = use ? x.y : q1; q2 = use ? x.z : q2;
     }
     q[0] = q0; q[1] = q1; q[2] = q2;
 }
