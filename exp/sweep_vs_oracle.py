@@ -1,0 +1,55 @@
+"""Exhaustive parity sweep: every unit of several multi-million-unit workloads against the C oracle."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import tri_oracle
+from pose2sim_amd import skeletons, synth
+from pose2sim_amd.engine import Engine
+
+_, _, swap26 = skeletons.keypoints('HALPE_26')
+eng = Engine(0)
+threads = min(128, len(os.sched_getaffinity(0)))
+cases = [
+    dict(name='cfg2', F=100_000, C=8, K=26, min_cams=2, seed=2),
+    dict(name='c8 min4 heavy', F=60_000, C=8, K=26, min_cams=4, seed=3, gen=dict(p_outlier=0.10, p_lowlik=0.10)),
+    dict(name='c6 swap', F=80_000, C=6, K=26, min_cams=2, seed=4, lr_swap=True),
+    dict(name='c5 undistort', F=80_000, C=5, K=26, min_cams=2, seed=5, undistort=True),
+    dict(name='c3', F=150_000, C=3, K=26, min_cams=2, seed=6),
+    dict(name='c2', F=150_000, C=2, K=26, min_cams=2, seed=7),
+    dict(name='c16 k131 min3', F=12_000, C=16, K=131, min_cams=3, seed=8),
+    dict(name='c7 undistort swap', F=40_000, C=7, K=26, min_cams=3, seed=9, undistort=True, lr_swap=True),
+    dict(name='c8 f64 inputs', F=40_000, C=8, K=26, min_cams=2, seed=10, f64=True),
+]
+import sys as _s
+sel = _s.argv[1:]
+for cs in cases:
+    if sel and not any(x in cs['name'] for x in sel):
+        continue
+    und, sw = cs.get('undistort', False), cs.get('lr_swap', False)
+    K = cs['K']
+    swap = swap26 if K == 26 else list(range(K))
+    wl = synth.make_config(cs['F'], cs['C'], K, 1, seed=cs['seed'], undistort=und, lr_swap=sw, swap_idx=swap, **cs.get('gen', {}))
+    xyl = wl['xyl'].astype(np.float64) + (1e-9 if cs.get('f64') else 0.0)
+    eng.set_calibration(wl['P'], wl['cams'] if und else None)
+    prm = eng.tri_params(15.0, 0.3, cs['min_cams'], und, sw)
+    t0 = time.time()
+    Q, err, nex, mask = eng.triangulate(xyl if cs.get('f64') else wl['xyl'], prm, swap if sw else None)
+    t1 = time.time()
+    Qr, er, nr, mr = tri_oracle.triangulate_batch(xyl, wl['P'], wl['cams'] if und else None, swap, 0.3, 15.0, cs['min_cams'], sw, und, threads=threads)
+    t2 = time.time()
+    Q = Q.reshape(-1, 3); Qr = Qr.reshape(-1, 3); err = err.reshape(-1).astype(np.float64); er = er.reshape(-1)
+    nan_mis = int((np.isnan(err) != np.isnan(er)).sum())
+    nex_mis = int((nex.reshape(-1).astype(np.int64) != nr.reshape(-1)).sum())
+    mask_mis = int((mask.reshape(-1).astype(np.uint32) != mr.reshape(-1).astype(np.uint32)).sum())
+    ok = ~np.isnan(er) & ~np.isnan(err)
+    d = np.linalg.norm(Q[ok] - Qr[ok], axis=1)
+    de = np.abs(err[ok] - er[ok]) / np.maximum(1.0, np.abs(er[ok]))
+    print(f"{cs['name']:20s} units {len(er):8d} valid {ok.sum():8d} nan_mis {nan_mis} nex_mis {nex_mis} mask_mis {mask_mis} "
+          f"max dQ {d.max():.2e} (>1e-7: {(d > 1e-7).sum()}) max dErr {de.max():.2e}  gpu {t1 - t0:.1f}s oracle {t2 - t1:.1f}s", flush=True)
+    if nan_mis or nex_mis or mask_mis or (d > 1e-7).any():
+        bad = np.flatnonzero((np.isnan(err) != np.isnan(er)) | (nex.reshape(-1).astype(np.int64) != nr.reshape(-1)) | (mask.reshape(-1).astype(np.uint32) != mr.reshape(-1).astype(np.uint32)))
+        for i in bad[:5]:
+            print('   unit', i, 'gpu', err[i], nex.reshape(-1)[i], bin(mask.reshape(-1)[i]), 'ref', er[i], nr.reshape(-1)[i], bin(mr.reshape(-1)[i]))
+        idx = np.flatnonzero(ok)[np.argsort(-d)[:3]]
+        for i in idx:
+            print('   far unit', i, 'd', np.linalg.norm(Q[i] - Qr[i]), '|Q|', np.linalg.norm(Qr[i]), 'err', err[i], er[i], bin(mask.reshape(-1)[i]))

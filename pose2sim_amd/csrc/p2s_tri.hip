@@ -166,13 +166,18 @@ __device__ __forceinline__ void smallest_eigvec(const double N[10], double q[3])
         const double den = fma(qq, qq, f * qp);
         const double rq = fast_rcp(qq);
         const double step = (den > 0.0) ? f * qq * fast_rcp(den) : f * rq;   // Halley, else Newton
-        // |error of lambda + step| <~ |f''/(2f')| step^2 (Newton's bound; Halley's is smaller),
-        // times |dq/dlambda| gives the error of the corrected q
+        // Error of the corrected q = q(lambda) + step dq/dlambda, two terms:
+        //  * |error of lambda + step| <~ |f''/(2f')| step^2 (Newton's bound; Halley's is smaller) times |dq/dlambda|
+        //  * the second-order term of q itself: |(M - lambda)^-1 dq/dlambda| step^2 <= |dq/dlambda| step^2 / (mu_1 - lambda),
+        //    with 1 / (mu_1 - lambda) = (mu_2 - lambda)(mu_3 - lambda) / det <= (tr / 2)^2 / det.  It only bites when M
+        //    has a weak direction (two cameras left), where it was worth up to 3e-7 m after a single pass.
         const double t = qp * step * step * rq;
-        const bool conv = pd && ((t * t * pp <= 1e-21 * qq) || (fabs(step) <= tol_abs));
+        const double tr = m00 + m11 + m22;
+        const double s2 = 0.25 * tr * tr * nid * step * step;
+        const bool conv = pd && (((t * t * pp <= 1e-21 * qq) && (s2 * s2 * pp <= 1e-21 * qq)) || (fabs(step) <= tol_abs));
         if (!done && pd) {
             q0 = fma(step, p0, y0); q1 = fma(step, p1, y1); q2 = fma(step, p2, y2);
-            weak = pp * 1e6 > qq - 1.0;     // |dq/dlambda| / |q| = 1 / (mu_1 - lambda) above 1e-3
+            weak = pp * c * c > 1e8;        // rounding noise of lambda (~1e-13 |c| in the worst cases seen) times |dq/dlambda|
         }
         double lam_new = lam + step;
         lo = (pd && f >= 0.0) ? lam : lo;
