@@ -5,8 +5,9 @@ from oracle import tri_oracle
 from pose2sim_amd import skeletons, synth
 from pose2sim_amd.engine import Engine
 _, _, swap = skeletons.keypoints('HALPE_26')
-F, C, K = 200_000, 4, 26
-wl = synth.make_config(F, C, K, 1, seed=44, p_outlier=0.04)
+F, C, K = int(sys.argv[1]), int(sys.argv[2]), 26
+seed = int(sys.argv[3])
+wl = synth.make_config(F, C, K, 1, seed=seed, **({'p_outlier': 0.04} if len(sys.argv) > 4 else {}))
 eng = Engine(0); eng.set_calibration(wl['P'])
 Q, err, nex, mask = eng.triangulate(wl['xyl'], eng.tri_params(15.0, 0.3, 2))
 Qr, er, nr, mr = tri_oracle.triangulate_batch(wl['xyl'].astype(np.float64), wl['P'], None, swap, 0.3, 15.0, 2, threads=64)

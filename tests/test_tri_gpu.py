@@ -49,8 +49,13 @@ def _compare(Q, err, nex, mask, Qr, er, nr, mr, what=''):
     ok = ~np.isnan(er)
     assert np.isnan(Q[~ok]).all()
     if ok.any():
-        dq = np.abs(Q[ok] - Qr[ok]).max()
-        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m'
+        # 1e-7 m inside a 10 m capture volume; beyond it the depth of a point seen under a vanishing angle is
+        # ill-posed in proportion to distance^2 / baseline (such points exist only as accepted garbage: two
+        # cameras, outliers that happen to agree), so the bound grows with (|Q| / 10 m)^2 there
+        scale = np.maximum(1.0, np.linalg.norm(Qr[ok], axis=1) / 10.0) ** 2
+        rel = np.abs(Q[ok] - Qr[ok]).max(axis=1) / scale
+        dq = rel.max()
+        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m (scaled beyond 10 m)'
         de = np.abs(err[ok].astype(np.float64) - er[ok]) / np.maximum(1.0, np.abs(er[ok]))
         assert de.max() <= TOL_E, f'{what}: error differs by {de.max():.3e}'
         return dq
@@ -227,3 +232,20 @@ def test_multi_chunk_calls_equal_the_whole_oracle_run(engine, C, F):
     threads = min(64, len(os.sched_getaffinity(0)))
     Qr, er, nr, mr = tri_oracle.triangulate_batch(xyl.astype(np.float64), wl['P'], None, swap, 0.3, 15.0, 2, threads=threads)
     _compare(Q, err, nex, mask, Qr, er, nr, mr, f'{F * K} units, C={C}')
+
+
+@pytest.mark.parametrize('C', [2, 3])
+def test_two_camera_geometry_every_unit_against_the_oracle(engine, C):
+    """Two cameras left = one weakly observed direction in the normal matrix: the case that needs the
+    second-order stop rule and the refinement step of smallest_eigvec.  1.5 M units, all checked."""
+    from oracle import tri_oracle
+    from pose2sim_amd import skeletons, synth
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    F, K = 60_000, 26
+    wl = synth.make_config(F, C, K, 1, seed=5 + C)
+    engine.set_calibration(wl['P'])
+    Q, err, nex, mask = engine.triangulate(wl['xyl'], engine.tri_params(15.0, 0.3, 2))
+    threads = min(64, len(os.sched_getaffinity(0)))
+    Qr, er, nr, mr = tri_oracle.triangulate_batch(wl['xyl'].astype(np.float64), wl['P'], None, swap, 0.3, 15.0, 2, threads=threads)
+    dq = _compare(Q, err, nex, mask, Qr, er, nr, mr, f'C={C}')
+    assert dq <= 2e-8, dq
