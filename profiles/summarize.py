@@ -23,12 +23,13 @@ def short(name):
 def counter_avg(subdir, counter):
     """kernel -> average counter value per dispatch (values of one dispatch are summed over its rows)."""
     per = {}
-    for path in glob.glob(os.path.join(SRC, subdir, '**', '*counter_collection.csv'), recursive=True):
+    paths = sorted(glob.glob(os.path.join(SRC, subdir, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)
+    for path in paths[-1:]:                                  # the latest run only
         with open(path) as fh:
             for row in csv.DictReader(fh):
                 if row['Counter_Name'] != counter:
                     continue
-                key = (short(row['Kernel_Name']), row['Dispatch_Id'])
+                key = (short(row['Kernel_Name']), path + ':' + row['Dispatch_Id'])
                 per[key] = per.get(key, 0.0) + float(row['Counter_Value'])
     out = {}
     for (k, _), v in per.items():
