@@ -271,8 +271,8 @@ def cpu_baseline_native(cfg, xyl, cams, P, swap, budget_frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 200 for the triangulation configs whose step is < 10 ms, 5 otherwise)')
+    ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
@@ -309,6 +309,11 @@ def main():
     from pose2sim_amd.engine import Engine, P2S_F32
 
     cfg = CONFIGS[args.config]
+    fast = args.config in ('cfg2', 'cfg2_clean', 'cfg4', 'single')
+    if args.steps is None:
+        args.steps = 200 if fast else 5
+    if args.warmup is None:
+        args.warmup = 10 if fast else 2
     if cfg.get('assoc') or cfg.get('single'):
         (bench_single if cfg.get('single') else bench_association)(args, cfg, rank, world, local_rank)
         if world > 1:
