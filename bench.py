@@ -291,10 +291,13 @@ def main():
     # rehearsal on a one-GPU box: P2S_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
     # (RCCL refuses two ranks on one device); the driver's multi-GPU runs never set it
     rehearsal = os.environ.get('P2S_BENCH_REHEARSAL') == '1'
+    # P2S_BENCH_FORCE_COLLECTIVE=1 (tests): run the multi-rank code path -- process group, packed asynchronous
+    # all-gather, max over ranks -- even with a single rank, so that the RCCL calls are exercised on one GPU
+    multi = world > 1 or os.environ.get('P2S_BENCH_FORCE_COLLECTIVE') == '1'
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if rehearsal:
             dist.init_process_group('gloo')
@@ -304,7 +307,7 @@ def main():
     import __graft_entry__ as entry
     if rank == 0:
         entry.build_hip()
-    if world > 1:
+    if multi:
         dist.barrier()
     from pose2sim_amd.engine import Engine, P2S_F32
 
@@ -316,7 +319,7 @@ def main():
         args.warmup = 10 if fast else 2
     if cfg.get('assoc') or cfg.get('single'):
         (bench_single if cfg.get('single') else bench_association)(args, cfg, rank, world, local_rank)
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
     xyl, cams, P, swap, K = make_workload(cfg, rank)
@@ -338,8 +341,8 @@ def main():
     off_n = off_m + n_units * 4
     nbytes = (off_n + n_units + 15) // 16 * 16
     # two result buffers: the all-gather of step i runs on RCCL's stream while step i+1 computes
-    d_outs = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
-    d_alls = [torch.empty(nbytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else []
+    d_outs = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2 if multi else 1)]
+    d_alls = [torch.empty(nbytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else []
     d_out = d_outs[0]
     base = d_out.data_ptr()
     pending = [None, None]
@@ -348,11 +351,11 @@ def main():
     def step():
         i = counter[0] % len(d_outs)
         counter[0] += 1
-        if world > 1 and pending[i] is not None:
+        if multi and pending[i] is not None:
             pending[i].wait()                      # buffer i is free again (its all-gather has finished)
         b = d_outs[i].data_ptr()
         eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, b, b + off_e, b + off_n, b + off_m)
-        if world > 1:
+        if multi:
             pending[i] = dist.all_gather_into_tensor(d_alls[i], d_outs[i], async_op=True)
 
     def drain():
@@ -368,7 +371,7 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -376,11 +379,11 @@ def main():
         step()
     drain()                                        # every all-gather of the K steps is inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -422,7 +425,7 @@ def main():
                        'params': {'thr_px': cfg['thr'], 'lik_thr': cfg['lik'], 'min_cams': cfg['min_cams'],
                                   'undistort': cfg['undistort'], 'lr_swap': cfg['lr_swap']},
                        'accepted_fraction': ok_frac, 'tile': eng.tri_geometry(K),
-                       'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if world > 1 else '')},
+                       'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': ('p2s_tri_level0_direct_kernel' if C <= 8 else 'p2s_tri_level0_kernel') + ' + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
@@ -438,7 +441,7 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

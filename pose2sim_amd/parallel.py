@@ -6,6 +6,8 @@ block [r*F/G, (r+1)*F/G); the only exchange step is ONE all-gather of the packed
 The sequential post-processing (tracking, interpolation, .trc) then runs on every rank's copy and
 only rank 0 writes files.
 """
+import os
+
 import numpy as np
 
 
@@ -55,7 +57,7 @@ def sharded_triangulate(compute, xyl):
     """
     rank, world = dist_info()
     F, Pn, K = xyl.shape[0], xyl.shape[1], xyl.shape[3]
-    if world == 1:
+    if world == 1 and not os.environ.get('P2S_FORCE_COLLECTIVE'):   # the variable: tests of the RCCL path on one GPU
         return compute(xyl)
     import torch
     import torch.distributed as dist

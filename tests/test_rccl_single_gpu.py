@@ -1,0 +1,74 @@
+"""The RCCL leg of the multi-GPU path on the one GPU a test box has: a process group with backend 'nccl' (= RCCL
+on ROCm) and world_size 1, through which parallel.sharded_triangulate and bench.py's asynchronous packed
+all-gather run exactly the calls the 8-GPU job makes (device tensors, uint8 payload, async handles).  The
+multi-rank logic itself (shard bounds, padding, reassembly) is covered on CPU with gloo and world_size 2 in
+test_distributed_cpu.py."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%%d' %% int(sys.argv[1]), rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    from pose2sim_amd import parallel, synth
+    from pose2sim_amd.engine import Engine
+    wl = synth.make_config(300, 5, 26, 2, seed=3)
+    eng = Engine(0); eng.set_calibration(wl['P'])
+    prm = eng.tri_params(15.0, 0.3, 2)
+    direct = eng.triangulate(wl['xyl'], prm)
+    os.environ['P2S_FORCE_COLLECTIVE'] = '1'
+    gathered = parallel.sharded_triangulate(lambda x: eng.triangulate(x, prm), wl['xyl'])
+    for a, b in zip(direct, gathered):
+        assert np.array_equal(a, b, equal_nan=True)
+    # bench.py's form: packed device buffer, asynchronous all-gather into a second buffer
+    n = 1 << 20
+    src = torch.arange(n, dtype=torch.int64, device='cuda').to(torch.uint8)
+    dst = torch.empty(n, dtype=torch.uint8, device='cuda')
+    work = dist.all_gather_into_tensor(dst, src, async_op=True)
+    work.wait(); torch.cuda.synchronize()
+    assert torch.equal(dst, src)
+    t = torch.tensor([1.5], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+    assert float(t.item()) == 1.5
+    dist.destroy_process_group()
+    print('RCCL-OK')
+''') % ROOT
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_one_rank(tmp_path):
+    import __graft_entry__ as entry
+    entry.build_hip()
+    script = tmp_path / 'rccl_one_rank.py'
+    script.write_text(SCRIPT)
+    port = 29500 + os.getpid() % 2000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, str(script), str(port)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and 'RCCL-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_with_one_rank():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, RANK / WORLD_SIZE from the
+    environment, backend nccl), with one rank: process group, double-buffered asynchronous all-gather of the
+    packed results inside the timed region, max over ranks."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', P2S_BENCH_FORCE_COLLECTIVE='1')
+    port = 29600 + os.getpid() % 2000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '10', '--warmup', '2',
+           '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 10 and line['value'] > 1e8
+    assert 'all-gather' in line['config']['parallelism']
