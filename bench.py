@@ -431,6 +431,11 @@ def main():
                          'kernel': ('p2s_tri_level0_direct_kernel' if C <= 8 else 'p2s_tri_level0_kernel') + ' + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }
+        if multi:
+            # the split a reader needs to judge the scaling: the all-gather moves 33 B per unit into every rank over
+            # xGMI (one link per peer), the kernels alone run at kernel_ms per step on every rank
+            out['collective'] = {'kind': 'all_gather_into_tensor (RCCL), async, double-buffered', 'bytes_per_rank_per_step': int(nbytes),
+                                 'value_kernels_only': n_units * world / (k_ms * 1e-3)}
         if not args.no_cpu_baseline and world == 1:
             frames = args.cpu_frames or {8: 400, 16: 12, 32: 8}.get(C, 100)
             out['cpu_baseline'] = cpu_baseline(cfg, xyl, cams, P, swap, frames)
