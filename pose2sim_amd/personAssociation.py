@@ -9,9 +9,10 @@ call and only the order-sensitive proposal extraction (person_index_per_cam, :51
 Single-person branch (:67-257): the brute-force search over "one person per camera" x "cameras
 switched off" on one tracked keypoint runs in the engine for every frame at once
 (``Engine.associate_single``); the host only gathers the tracked keypoint of every detected person and
-rewrites the JSON files.  With ``undistort_points`` the reference's own single-person code cannot run
-(triangulate_comb :130 indexes the per-camera lists with ``range(len(Q_comb))`` = 4 entries and raises
-for fewer than 4 kept cameras), so that combination is refused here with a clear message.
+rewrites the JSON files.  With ``undistort_points`` the reference's single-person code reprojects through
+``range(len(Q_comb))`` = the first 4 kept cameras only (triangulate_comb :130-132) and raises IndexError as soon
+as a combination keeps fewer than 4 cameras; that accident is not reproduced and the combination is refused
+here with a clear message.
 """
 import json
 import logging
@@ -146,8 +147,10 @@ def _associate_single_person(config_dict, frames_src, frames_dst, n_cams, P_all,
     likelihood_threshold = config_dict.get('personAssociation').get('likelihood_threshold_association')
     min_cameras_for_triangulation = config_dict.get('triangulation').get('min_cameras_for_triangulation')
     if config_dict.get('triangulation').get('undistort_points'):
-        raise NotImplementedError('single-person association with undistort_points: the reference itself fails there '
-                                  '(personAssociation.py:130); run the association on the distorted points.')
+        raise NotImplementedError('single-person association with undistort_points: the reference reprojects through '
+                                  'range(len(Q_comb)) = the first 4 kept cameras (personAssociation.py:130-132) and raises '
+                                  'IndexError as soon as a combination keeps fewer than 4; that behaviour is not reproduced. '
+                                  'Run the association on the distorted points (undistort_points = false).')
     try:
         tracked_keypoint_id = skeletons.node_id_by_name(pose_model, tracked_keypoint, config_dict)
         assert tracked_keypoint_id                       # id None and id 0 both land in the fallback, :749
