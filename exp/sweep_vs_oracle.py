@@ -19,6 +19,12 @@ cases = [
     dict(name='c16 k131 min3', F=12_000, C=16, K=131, min_cams=3, seed=8),
     dict(name='c7 undistort swap', F=40_000, C=7, K=26, min_cams=3, seed=9, undistort=True, lr_swap=True),
     dict(name='c8 f64 inputs', F=40_000, C=8, K=26, min_cams=2, seed=10, f64=True),
+    dict(name='c32 undistort swap', F=400, C=32, K=26, min_cams=2, seed=11, undistort=True, lr_swap=True, gen=dict(p_outlier=0.01, p_lowlik=0.03)),
+    dict(name='c32 min28', F=2000, C=32, K=26, min_cams=28, seed=12, gen=dict(p_outlier=0.03)),
+    dict(name='c24 min20 swap', F=2000, C=24, K=26, min_cams=20, seed=13, lr_swap=True),
+    dict(name='c20 min3', F=1500, C=20, K=26, min_cams=3, seed=14, gen=dict(p_outlier=0.01, p_lowlik=0.02)),
+    dict(name='c17 f64 undistort', F=3000, C=17, K=26, min_cams=12, seed=15, undistort=True, f64=True),
+    dict(name='c9 min2', F=30_000, C=9, K=26, min_cams=2, seed=16),
 ]
 import sys as _s
 sel = _s.argv[1:]

@@ -249,3 +249,27 @@ def test_two_camera_geometry_every_unit_against_the_oracle(engine, C):
     Qr, er, nr, mr = tri_oracle.triangulate_batch(wl['xyl'].astype(np.float64), wl['P'], None, swap, 0.3, 15.0, 2, threads=threads)
     dq = _compare(Q, err, nex, mask, Qr, er, nr, mr, f'C={C}')
     assert dq <= 2e-8, dq
+
+
+@pytest.mark.parametrize('name,F,C,min_cams,undistort,lr_swap,f64,gen', [
+    ('c32 undistort swap', 200, 32, 2, True, True, False, dict(p_outlier=0.01, p_lowlik=0.03)),
+    ('c32 min28', 1000, 32, 28, False, False, False, dict(p_outlier=0.03)),
+    ('c24 min20 swap', 1000, 24, 20, False, True, False, {}),
+    ('c17 f64 undistort', 1500, 17, 12, True, False, True, {}),
+    ('c9', 10_000, 9, 2, False, False, False, {}),
+])
+def test_many_cameras_every_unit_against_the_oracle(engine, name, F, C, min_cams, undistort, lr_swap, f64, gen):
+    """Camera counts above the direct kernel's 8 (tiled level-0 kernel, search groups of up to 64 lanes and several
+    rounds per level, swap and undistortion at C = 32 as in BASELINE configs[4])."""
+    from oracle import tri_oracle
+    from pose2sim_amd import skeletons, synth
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    wl = synth.make_config(F, C, 26, 1, seed=100 + C, undistort=undistort, lr_swap=lr_swap, swap_idx=swap, **gen)
+    x64 = wl['xyl'].astype(np.float64) + (1e-9 if f64 else 0.0)
+    engine.set_calibration(wl['P'], wl['cams'] if undistort else None)
+    prm = engine.tri_params(15.0, 0.3, min_cams, undistort, lr_swap)
+    Q, err, nex, mask = engine.triangulate(x64 if f64 else wl['xyl'], prm, swap if lr_swap else None)
+    threads = min(64, len(os.sched_getaffinity(0)))
+    Qr, er, nr, mr = tri_oracle.triangulate_batch(x64, wl['P'], wl['cams'] if undistort else None, swap, 0.3, 15.0, min_cams,
+                                                  lr_swap, undistort, threads=threads)
+    _compare(Q, err, nex, mask, Qr, er, nr, mr, name)
