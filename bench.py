@@ -428,7 +428,7 @@ def main():
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': ('p2s_tri_level0_direct_kernel' if C <= 8 else 'p2s_tri_level0_kernel') + ' + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
+                         'kernel': ('p2s_tri_level0_direct_kernel' if (C <= 8 or (C <= 16 and not cfg['lr_swap'])) else 'p2s_tri_level0_kernel') + ' + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }
         if multi:

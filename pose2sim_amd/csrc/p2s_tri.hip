@@ -21,6 +21,7 @@
 //
 // Everything is data-parallel fp64 VALU work on an HBM-streamed tensor: no MFMA (4x4 systems).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <math.h>
 
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(256, 4) p2s_tri_level0_kernel(const P2sTriArgs
 // once.  Without a staged tile the waves of a CU are independent: the ~2 us HBM latency of one wave
 // hides under the arithmetic of the others instead of stalling a whole workgroup at a barrier.
 template <typename T, bool UNDISTORT, bool LRSWAP, int CT>
-__global__ void __launch_bounds__(256, 4) p2s_tri_level0_direct_kernel(const P2sTriArgs a) {
+__global__ void __launch_bounds__(256, (CT <= 8 ? 4 : 3)) p2s_tri_level0_direct_kernel(const P2sTriArgs a) {
     const int C = a.C, K = a.K;
     cam_cptr cams = (cam_cptr)a.cams;
     const int lane = threadIdx.x & 63;
@@ -1258,6 +1259,14 @@ static hipError_t launch_level0(const P2sTriArgs &a, const P2sTriLaunch &g, hipS
         const unsigned grid = (unsigned)((n_units + 255) / 256);
         hipLaunchKernelGGL((p2s_tri_level0_direct_kernel<T, U, L, 8>), dim3(grid), dim3(256), 0, s, a);
         return hipGetLastError();
+    }
+    if constexpr (sizeof(T) == 4 && !L) {    // 16 float32 triplets still fit in registers at 3 waves per SIMD (not with the swapped copy)
+        if (a.C <= 16 && !g.force_tiled) {
+            const int64_t n_units = a.n_blocks * a.K;
+            const unsigned grid = (unsigned)((n_units + 255) / 256);
+            hipLaunchKernelGGL((p2s_tri_level0_direct_kernel<T, U, L, 16>), dim3(grid), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_tri_level0_kernel<T, U, L>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, g.lds0);
