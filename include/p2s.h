@@ -150,6 +150,7 @@ typedef struct p2s_single_params {
  * The product of the per-camera person counts of a frame must not exceed P2S_MAX_COMBINATIONS. */
 #define P2S_MAX_PERSONS_PER_CAM 16
 #define P2S_MAX_COMBINATIONS (1 << 20)
+#define P2S_MAX_SINGLE_SEARCH 2147483648.0  /* worst-case (combination, camera subset) evaluations per frame */
 int p2s_associate_single_device(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, const int32_t *d_n_persons,
                                 const int64_t *d_offsets, const void *d_tracked, const p2s_single_params *params,
                                 int32_t *d_comb, double *d_err, double *d_Q);

@@ -546,6 +546,19 @@ int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, con
         }
         if (prod > (double)P2S_MAX_COMBINATIONS)
             return fail(P2S_ERR_INVALID_ARG, "frame %lld: %.0f person combinations exceed %d", (long long)f, prod, P2S_MAX_COMBINATIONS);
+        // worst case of the search (no combination ever gets under the threshold): every combination x every
+        // subset of up to (cameras with detections - min_cameras) cameras switched off.  The reference would
+        // run just as long; a frame that could keep one wave busy for minutes is refused instead.
+        int present = 0;
+        for (int c = 0; c < C; ++c) present += n_persons[f * C + c] > 0;
+        double subsets = 0.0, binom = 1.0;
+        for (int k = 0; k <= present - params->min_cameras; ++k) {
+            subsets += binom;
+            binom = binom * (present - k) / (k + 1);
+        }
+        if (prod * subsets > P2S_MAX_SINGLE_SEARCH)
+            return fail(P2S_ERR_INVALID_ARG, "frame %lld: up to %.3g (combination, camera subset) evaluations exceed %.3g; raise "
+                        "min_cameras_for_triangulation or reduce the detections", (long long)f, prod * subsets, (double)P2S_MAX_SINGLE_SEARCH);
     }
     if (offsets[n_frames] != rows) return fail(P2S_ERR_INVALID_ARG, "offsets[F] does not match n_persons");
     if (rows > 0 && !tracked) return fail(P2S_ERR_INVALID_ARG, "null tracked");

@@ -18,6 +18,7 @@ struct P2sCam {
     double center[3];      // -R^T T                            (association rays)
 };
 
+#define P2S_MAX_SUBSETS_PER_LEVEL (1u << 26)   // search kernel: deeper levels are not entered (see p2s_tri.hip)
 // The work list is cut into shards (workgroup b appends to shard b % P2S_WL_SHARDS) so that the
 // append counters do not serialise: one returning atomic per wave on ONE word caps near 90 per us.
 #define P2S_WL_SHARDS 128

@@ -1056,7 +1056,10 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 if (is_owner_now) {
                     err_min = r_err; Qb[0] = r_q0; Qb[1] = r_q1; Qb[2] = r_q2;
                     mask = r_mask; n_excl = r_nexcl;
-                    cont = (err_min > thr) && (level + 1 <= Lmax) && (a.debug_mode != 3);
+                    // safety valve: a level with more than 2^26 subsets (C(32, 10) and beyond) is not entered -- the
+                    // reference would need hours of CPU for that one keypoint; the unit ends as "not triangulated"
+                    cont = (err_min > thr) && (level + 1 <= Lmax) && (a.debug_mode != 3) &&
+                           (sBinom[C * 33 + level + 1] <= P2S_MAX_SUBSETS_PER_LEVEL);
                 }
             }
             pend_level = __ballot(cont);

@@ -181,3 +181,8 @@ def test_single_person_edge_cases(engine):
     assert (comb == -1).all() and np.isinf(err).all() and np.isnan(Q).all()
     with pytest.raises(P2sError):
         eng.associate_single(np.full((1, 4), 17, np.int32), np.zeros((68, 3)), 10.0, 0.3, 2)
+    # 3^12 combinations x 4083 camera subsets in the worst case: refused before anything is launched
+    cams12 = synth.make_cameras(12, seed=9)
+    eng.set_calibration(np.array(synth.projection_matrices(cams12)))
+    with pytest.raises(P2sError, match='evaluations exceed'):
+        eng.associate_single(np.full((1, 12), 3, np.int32), np.zeros((36, 3)), 10.0, 0.3, 2)
