@@ -15,6 +15,7 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" --no-cpu-baseline > "$OUT/trace.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_valu" -- python "$ROOT/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/pmc_valu.log" 2>&1
 cd "$ROOT"
 python profiles/summarize.py "$R" > "$OUT/summary.log" 2>&1
 tail -5 "$OUT/summary.log"

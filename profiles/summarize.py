@@ -43,6 +43,20 @@ stats = glob.glob(os.path.join(SRC, 'trace', '**', '*kernel_stats.csv'), recursi
 if stats:
     shutil.copy(stats[0], os.path.join(DST, 'kernel_stats_cfg2.csv'))
 
+# instruction mix / issue utilisation per kernel
+names = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY']
+valu = {n: counter_avg('pmc_valu', n)[0] for n in names}
+kernels = sorted(k for k in valu['SQ_WAVES'] if k.startswith('p2s_'))
+if kernels:
+    with open(os.path.join(DST, 'pmc_valu_cfg2.csv'), 'w') as fh:
+        fh.write('kernel,' + ','.join(names) + ',valu_insts_per_wave,valu_issue_us_at_2.4GHz(insts*4.15cyc/1024 SIMDs)\n')
+        for k in kernels:
+            vals = [valu[n].get(k, 0.0) for n in names]
+            per_wave = vals[1] / max(vals[0], 1.0)
+            issue_us = vals[1] * 4.15 / 1024.0 / 2400.0
+            fh.write(k + ',' + ','.join('%.0f' % v for v in vals) + ',%.1f,%.1f\n' % (per_wave, issue_us))
+            print(k, 'VALU insts/wave %.1f' % per_wave, 'issue time %.1f us' % issue_us)
+
 fetch, nf = counter_avg('pmc_fetch', 'FETCH_SIZE')
 write, _ = counter_avg('pmc_write', 'WRITE_SIZE')
 rows, total = [], 0.0
