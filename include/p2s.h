@@ -205,6 +205,15 @@ int p2s_json_gather_keypoints(const p2s_json_batch *batch, const int32_t *keypoi
 int p2s_json_gather_people(const p2s_json_batch *batch, const int64_t *file_index, const int32_t *person_index,
                            int64_t n_rows, int32_t n_values, int32_t dtype, void *out, int64_t *n_inexact);
 
+/* ---- .trc data rows (host threads) ---------------------------------------------------------------------------
+ * Replaces DataFrame.to_csv in make_trc (triangulation.py:214): appends n_rows lines
+ * `frames[r] \t repr(time[r]) \t repr(data[r][0]) \t ...\n` to the file (the 5 header lines are written by the
+ * caller), floats exactly as Python's repr() prints them, NaN as an empty field. */
+int p2s_trc_append_rows(const char *path, int64_t n_rows, int32_t n_cols, const int64_t *frames, const double *time,
+                        const double *data, int32_t n_threads);
+/* repr(float) of one value into out (>= 32 bytes, NUL-terminated); returns the length.  For tests. */
+int p2s_format_float_repr(double value, char *out, int32_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,9 @@ import numpy as np
 
 def dist_info():
     """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use."""
+    import sys
+    if 'torch' not in sys.modules and 'WORLD_SIZE' not in os.environ:
+        return 0, 1                  # single process that never touched torch: do not pay its import (~2-5 s)
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():

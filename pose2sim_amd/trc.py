@@ -97,8 +97,27 @@ def make_trc(config_dict, Q, keypoints_names, id_person=-1):
     with open(trc_path, 'w') as trc_o:
         for line in header_trc:
             trc_o.write(line + '\n')
-        Q.to_csv(trc_o, sep='\t', index=True, header=None, lineterminator='\n')
+    # the data rows: DataFrame.to_csv(sep='\t', index=True, header=None, lineterminator='\n') of the reference
+    # (:214), written by the native formatter (csrc/p2s_trc.cpp: repr() floats, NaN -> empty field)
+    write_rows(trc_path, np.asarray(Q.index), Q.iloc[:, 0].to_numpy(), Q.iloc[:, 1:].to_numpy())
     return trc_path
+
+
+def write_rows(trc_path, frames, time_col, data):
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    frames = np.ascontiguousarray(frames)
+    if not np.issubdtype(frames.dtype, np.integer):
+        raise ValueError('frame numbers must be integers')
+    frames = frames.astype(np.int64, copy=False)
+    time_col = np.ascontiguousarray(time_col, dtype=np.float64)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    n_rows = len(frames)
+    if time_col.shape != (n_rows,) or data.ndim != 2 or data.shape[0] != n_rows:
+        raise ValueError('frames, time and data disagree on the number of rows')
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None    # noqa: E731
+    _lib.check(lib.p2s_trc_append_rows(os.fsencode(trc_path), n_rows, data.shape[1], ptr(frames), ptr(time_col), ptr(data), 0))
 
 
 def read_trc(trc_path):
