@@ -214,6 +214,18 @@ int p2s_trc_append_rows(const char *path, int64_t n_rows, int32_t n_cols, const 
 /* repr(float) of one value into out (>= 32 bytes, NUL-terminated); returns the length.  For tests. */
 int p2s_format_float_repr(double value, char *out, int32_t capacity);
 
+/* ---- associated-pose JSON files (host threads) -----------------------------------------------------------------
+ * rewrite_json_files (personAssociation.py:552-580) for n_files (source, destination) pairs at once: destination =
+ * json.dumps of the source document with 'people' replaced by the selected persons -- sel[sel_offsets[i] ..
+ * sel_offsets[i+1]) holds, per proposal, the index of the person in the source's 'people' list or -1 for {} --
+ * in Python's text (', ' / ': ' separators, ensure_ascii escapes, repr() floats, first-position / last-value for
+ * repeated keys).  Whenever the reference would raise (unreadable or invalid source, no 'people' list, index out
+ * of range) the destination is removed, as there.  Paths as in p2s_json_parse.  written [n_files] (may be NULL):
+ * 1 = file written, 0 = removed. */
+int p2s_json_rewrite_people(const char *src_paths, const int64_t *src_offsets, const char *dst_paths,
+                            const int64_t *dst_offsets, int64_t n_files, const int64_t *sel_offsets, const int32_t *sel,
+                            int32_t n_threads, int8_t *written);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,8 @@ SIGNATURES = {
                                             C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]),
     'p2s_json_gather_people': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_void_p, C.POINTER(C.c_int64)]),
+    'p2s_json_rewrite_people': (C.c_int, [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_int32, C.c_void_p]),
     'p2s_trc_append_rows': (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'p2s_format_float_repr': (C.c_int, [C.c_double, C.c_char_p, C.c_int32]),
     'p2s_tri_geometry': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -56,7 +56,8 @@ def person_index_per_cam(affinity, cum_persons_per_view, min_cameras_for_triangu
 
 def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
     """personAssociation.py:552-580: people reordered by proposal, {} where a camera does not see
-    the person; an unreadable source leaves no output file."""
+    the person; an unreadable source leaves no output file.  Per-frame Python form, kept as the statement the
+    native batch writer below is tested against (tests/test_rewrite_json.py); associate_all uses the batch."""
     for cam in range(n_cams):
         try:
             with open(json_tracked_files_f[cam], 'w') as json_tracked_f:
@@ -72,6 +73,38 @@ def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
                 json_tracked_f.write(json.dumps(js_new))
         except Exception:
             os.remove(json_tracked_files_f[cam])
+
+
+def rewrite_json_files_batch(dst_files, src_files, proposals_per_frame, n_cams):
+    """rewrite_json_files for every frame of the trial in one native call (csrc/p2s_rewrite.cpp): same text as
+    json.dumps, same "remove the output on any error" rule, on host threads.
+    dst_files / src_files: [F][n_cams] paths; proposals_per_frame[f]: array [n_proposals][n_cams] with NaN = unseen."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    src, dst, sel, sel_off = [], [], [], [0]
+    for f, proposals in enumerate(proposals_per_frame):
+        proposals = np.asarray(proposals, dtype=float).reshape(-1, n_cams) if np.asarray(proposals).size else np.zeros((0, n_cams))
+        for cam in range(n_cams):
+            src.append(os.fsencode(src_files[f][cam]))
+            dst.append(os.fsencode(dst_files[f][cam]))
+            col = proposals[:, cam]
+            sel.extend(np.where(np.isnan(col), -1, col).astype(np.int64).tolist())
+            sel_off.append(len(sel))
+    n = len(src)
+    if n == 0:
+        return
+
+    def pack(paths):
+        off = np.zeros(len(paths) + 1, dtype=np.int64)
+        np.cumsum([len(p) for p in paths], out=off[1:])
+        return b''.join(paths), off
+    sblob, soff = pack(src)
+    dblob, doff = pack(dst)
+    sel = np.ascontiguousarray(sel, dtype=np.int32)
+    sel_off = np.ascontiguousarray(sel_off, dtype=np.int64)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None    # noqa: E731
+    _lib.check(lib.p2s_json_rewrite_people(sblob, ptr(soff), dblob, ptr(doff), n, ptr(sel_off), ptr(sel), 0, None))
 
 
 def recap_tracking(config_dict, error=0, nb_cams_excluded=0):
@@ -177,13 +210,14 @@ def _associate_single_person(config_dict, frames_src, frames_dst, n_cams, P_all,
     comb, err, _ = engine.associate_single(n_persons, tracked, error_threshold_tracking, likelihood_threshold,
                                            min_cameras_for_triangulation)
 
-    error_min_tot, cameras_off_tot = [], []
+    error_min_tot, cameras_off_tot, proposals_all = [], [], []
     for fi in range(F):
         proposal = np.where(comb[fi] < 0, np.nan, comb[fi].astype(float))
         if not np.isinf(err[fi]):
             error_min_tot.append(err[fi])
         cameras_off_tot.append(float(np.count_nonzero(np.isnan(proposal))))
-        rewrite_json_files(frames_dst[fi], frames_src[fi], [proposal], n_cams)
+        proposals_all.append([proposal])
+    rewrite_json_files_batch(frames_dst, frames_src, proposals_all, n_cams)      # every file of the trial, host threads
     return error_min_tot, cameras_off_tot
 
 
@@ -274,10 +308,11 @@ def associate_all(config_dict):
     prm = engine.assoc_params(reconstruction_error_threshold, min_affinity, min_cameras_for_triangulation)
     affinity = engine.associate(n_persons, kpts, prm)
 
+    proposals_all = []
     for fi in range(len(frames)):
         cum = np.cumsum([0] + list(n_persons[fi]))
         N = int(cum[-1])
-        proposals = person_index_per_cam(affinity[fi, :N, :N], cum, min_cameras_for_triangulation)
-        rewrite_json_files(dst_files[fi], src_files[fi], proposals, n_cams)
+        proposals_all.append(person_index_per_cam(affinity[fi, :N, :N], cum, min_cameras_for_triangulation))
+    rewrite_json_files_batch(dst_files, src_files, proposals_all, n_cams)         # every file of the trial, host threads
 
     recap_tracking(config_dict)

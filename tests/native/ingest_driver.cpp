@@ -52,6 +52,32 @@ int main(int argc, char **argv) {
         }
     std::vector<double> rows(fi.size() * 9 + 1);
     if (p2s_json_gather_people(b, fi.data(), pi.data(), (int64_t)fi.size(), 9, P2S_F64, rows.data(), &bad) != P2S_OK) return 7;
+    // rewrite every file with the selection (person 0, {}, person 1, person 2) into <path>.out
+    {
+        std::string dblob;
+        std::vector<int64_t> doff{0}, soff{0};
+        std::vector<int32_t> sel;
+        for (int64_t i = 0; i < n; ++i) {
+            dblob.append(blob, (size_t)off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]));
+            if (off[(size_t)i + 1] > off[(size_t)i]) dblob += ".out";
+            doff.push_back((int64_t)dblob.size());
+            const int32_t pick[4] = {0, -1, 1, 2};
+            for (int k = 0; k < (int)(i % 5); ++k) sel.push_back(pick[k % 4]);
+            soff.push_back((int64_t)sel.size());
+        }
+        std::vector<int8_t> written((size_t)n + 1);
+        if (p2s_json_rewrite_people(blob.data(), off.data(), dblob.data(), doff.data(), n, soff.data(), sel.data(), threads,
+                                    written.data()) != P2S_OK) return 8;
+        char tmp[64];
+        p2s_format_float_repr(0.1, tmp, 64);
+        const char *trc = argc > 2 ? argv[2] : nullptr;
+        if (trc) {
+            std::vector<int64_t> fr(100);
+            std::vector<double> tm(100), dat(100 * 7);
+            for (int r = 0; r < 100; ++r) { fr[(size_t)r] = r; tm[(size_t)r] = r / 60.0; for (int c = 0; c < 7; ++c) dat[(size_t)r * 7 + c] = (r % 9 == 0) ? 0.0 / 0.0 : r * 1e-3 * (c - 3); }
+            if (p2s_trc_append_rows(trc, 100, 7, fr.data(), tm.data(), dat.data(), threads) != P2S_OK) return 9;
+        }
+    }
     long ok = 0;
     for (int64_t i = 0; i < n; ++i) ok += counts[(size_t)i] >= 0;
     printf("files %lld readable %ld people %lld\n", (long long)n, ok, (long long)base[(size_t)n]);

@@ -1,5 +1,5 @@
-"""The JSON parser reads files a user hands it, so it is also run under AddressSanitizer + UBSan (host build,
-g++): the acceptance corpus of test_ingest.py plus a few thousand random mutations of valid documents
+"""The JSON parser and rewriter read files a user hands them, so the host code (ingest, associated-pose writer,
+.trc rows) is also run under AddressSanitizer + UBSan (host build, g++): the acceptance corpus of test_ingest.py plus a few thousand random mutations of valid documents
 (truncations, byte flips, duplicated slices).  Any out-of-bounds access, leak or undefined behaviour fails."""
 import os
 import random
@@ -17,7 +17,8 @@ def driver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp('asan') / 'ingest_driver')
     cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer', '-pthread',
            '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'native', 'ingest_driver.cpp'),
-           os.path.join(ROOT, 'pose2sim_amd', 'csrc', 'p2s_ingest.cpp'), '-o', exe]
+           os.path.join(ROOT, 'pose2sim_amd', 'csrc', 'p2s_ingest.cpp'), os.path.join(ROOT, 'pose2sim_amd', 'csrc', 'p2s_rewrite.cpp'),
+           os.path.join(ROOT, 'pose2sim_amd', 'csrc', 'p2s_trc.cpp'), '-o', exe]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
 
@@ -54,7 +55,7 @@ def test_parser_under_asan_and_ubsan(driver, tmp_path):
     paths += [str(tmp_path / 'missing.json'), '', str(tmp_path)]
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1')
     for threads in ('1', '8'):
-        r = subprocess.run([driver, threads], input='\n'.join(paths) + '\n', capture_output=True, text=True, env=env, timeout=600)
+        r = subprocess.run([driver, threads, str(tmp_path / f'rows_{threads}.trc')], input='\n'.join(paths) + '\n', capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
         assert 'runtime error' not in r.stderr and 'AddressSanitizer' not in r.stderr, r.stderr[-4000:]
         assert r.stdout.startswith(f'files {len(paths)} ')
