@@ -226,6 +226,15 @@ int p2s_json_rewrite_people(const char *src_paths, const int64_t *src_offsets, c
                             const int64_t *dst_offsets, int64_t n_files, const int64_t *sel_offsets, const int32_t *sel,
                             int32_t n_threads, int8_t *written);
 
+/* ---- proposals from the association result, first half (host threads) -----------------------------------------
+ * The per-detection rows of person_index_per_cam (personAssociation.py:512-527) for every frame: rows[f][r][c] =
+ * np.argmax of detection r's affinities to camera c's detections, -1 when camera c has none or none is positive.
+ * rows [F][n_max][C] (the first sum(n_persons[f]) rows of a frame are written).  The order-sensitive second half
+ * (np.unique / np.argsort / first-come filter, :528-549) stays with the caller in NumPy: np.argsort's order among
+ * equal counts is unspecified and build-dependent, and it decides the person order in the output files. */
+int p2s_assoc_argmax_rows(int64_t n_frames, int32_t n_cams, int32_t n_max, const double *affinity, const int32_t *n_persons,
+                          int32_t n_threads, int32_t *rows);
+
 #ifdef __cplusplus
 }
 #endif

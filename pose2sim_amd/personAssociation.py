@@ -40,7 +40,13 @@ def person_index_per_cam(affinity, cum_persons_per_view, min_cameras_for_triangu
             block = affinity[r, cum_persons_per_view[cam]:cum_persons_per_view[cam + 1]]
             row += [np.argmax(block) if (len(block) > 0 and max(block) > 0) else -1]
         rows.append(row)
-    proposals = np.array(rows, dtype=float)
+    return proposals_from_rows(np.array(rows, dtype=float), min_cameras_for_triangulation)
+
+
+def proposals_from_rows(proposals, min_cameras_for_triangulation):
+    """Second half of person_index_per_cam (:528-549), the NumPy calls of the reference as they are: np.argsort's
+    order among equal counts is unspecified (and not stable in NumPy 2.x's SIMD sorts), so no re-implementation can
+    promise the same person order -- the same calls can."""
     if proposals.size == 0:
         return np.array([])
     proposals, nb_detections = np.unique(proposals, axis=0, return_counts=True)
@@ -52,6 +58,25 @@ def person_index_per_cam(affinity, cum_persons_per_view, min_cameras_for_triangu
     proposals = proposals[mask]
     nb_cams_per_person = [np.count_nonzero(~np.isnan(p)) for p in proposals]
     return np.array([p for (n, p) in zip(nb_cams_per_person, proposals) if n >= min_cameras_for_triangulation])
+
+
+def proposals_batch(affinity, n_persons, min_cameras_for_triangulation):
+    """person_index_per_cam for every frame: the per-detection argmax rows of all frames in one native call
+    (csrc/p2s_proposals.cpp, the Python double loop of :516-527), then the reference's NumPy calls per frame.
+    affinity [F][n_max][n_max], n_persons [F][C] -> list of float arrays [n_proposals][C] (NaN = unseen)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    affinity = np.ascontiguousarray(affinity, dtype=np.float64)
+    n_persons = np.ascontiguousarray(n_persons, dtype=np.int32)
+    F, n_cams = n_persons.shape
+    n_max = affinity.shape[1] if affinity.ndim == 3 else 0
+    rows = np.full((F, n_max, n_cams), -1, dtype=np.int32)
+    if F and n_max:
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)    # noqa: E731
+        _lib.check(lib.p2s_assoc_argmax_rows(F, n_cams, n_max, ptr(affinity), ptr(n_persons), 0, ptr(rows)))
+    totals = n_persons.sum(axis=1)
+    return [proposals_from_rows(rows[f, :int(totals[f])].astype(float), min_cameras_for_triangulation) for f in range(F)]
 
 
 def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
@@ -308,11 +333,7 @@ def associate_all(config_dict):
     prm = engine.assoc_params(reconstruction_error_threshold, min_affinity, min_cameras_for_triangulation)
     affinity = engine.associate(n_persons, kpts, prm)
 
-    proposals_all = []
-    for fi in range(len(frames)):
-        cum = np.cumsum([0] + list(n_persons[fi]))
-        N = int(cum[-1])
-        proposals_all.append(person_index_per_cam(affinity[fi, :N, :N], cum, min_cameras_for_triangulation))
+    proposals_all = proposals_batch(affinity, n_persons, min_cameras_for_triangulation)        # host threads
     rewrite_json_files_batch(dst_files, src_files, proposals_all, n_cams)         # every file of the trial, host threads
 
     recap_tracking(config_dict)
