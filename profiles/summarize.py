@@ -39,9 +39,9 @@ def counter_avg(subdir, counter):
 
 for f in glob.glob(os.path.join(SRC, 'bench_*.json')):
     shutil.copy(f, DST)
-stats = glob.glob(os.path.join(SRC, 'trace', '**', '*kernel_stats.csv'), recursive=True)
+stats = sorted(glob.glob(os.path.join(SRC, 'trace', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(DST, 'kernel_stats_cfg2.csv'))
+    shutil.copy(stats[-1], os.path.join(DST, 'kernel_stats_cfg2.csv'))
 
 # instruction mix / issue utilisation per kernel
 names = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY']
