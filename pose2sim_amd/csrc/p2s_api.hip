@@ -448,6 +448,7 @@ int p2s_associate_device(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, in
     a.cams = ctx->d_cams;
     a.n_frames = n_frames; a.C = ctx->n_cams; a.Kj = n_kpts_json; a.Nmax = n_max;
     a.max_iter = params->max_iter;
+    if (const char *dbg = getenv("P2S_DEBUG_MODE")) a.debug_mode = atoi(dbg);   // diagnostics only
     a.recon_thr = params->reconstruction_error_threshold; a.min_affinity = params->min_affinity;
     a.w_rank = params->w_rank; a.tol = params->tol; a.w_sparse = params->w_sparse;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -39,6 +39,28 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Sum over the L consecutive lanes of a column pair with DPP moves (L = 2, 4, 8, 16): quad permutes for the first
+// two stages, then row_half_mirror / row_mirror, which pair each lane with one that holds the other half's sum.
+// ~10 cycles per stage against a ~120-cycle LDS round trip for ds_bpermute, and the Jacobi step is one long
+// dependent chain.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+template <int L>
+__device__ __forceinline__ void group_sum3(double &a, double &b, double &c) {
+    if constexpr (L >= 2) { a += dpp_move<0xB1>(a); b += dpp_move<0xB1>(b); c += dpp_move<0xB1>(c); }      // quad_perm [1,0,3,2]
+    if constexpr (L >= 4) { a += dpp_move<0x4E>(a); b += dpp_move<0x4E>(b); c += dpp_move<0x4E>(c); }      // quad_perm [2,3,0,1]
+    if constexpr (L >= 8) { a += dpp_move<0x141>(a); b += dpp_move<0x141>(b); c += dpp_move<0x141>(c); }   // row_half_mirror
+    if constexpr (L >= 16) { a += dpp_move<0x140>(a); b += dpp_move<0x140>(b); c += dpp_move<0x140>(c); }  // row_mirror
+    if constexpr (L >= 32) {
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64); c += __shfl_xor(c, 16, 64);
+    }
+}
+
 // round-robin (circle method) pairing: step s of n-1, pair k of n/2 -> columns (p, q), n even
 __device__ __forceinline__ void rr_pair(int n, int s, int k, int &p, int &q) {
     const int m = n - 1;
@@ -54,34 +76,38 @@ __device__ __forceinline__ void rr_pair(int n, int s, int k, int &p, int &q) {
 // RPL = rows per lane (compile time): the RPL column elements a lane owns are read with one batch of
 // LDS loads and held in registers, so a round-robin step costs two LDS round trips instead of 4*RPL.
 template <int RPL, int L>
-__device__ void jacobi_svd_t(double *A, double *V, int n, int lane) {
+__device__ void jacobi_svd_t(double *A, double *V, int n, int ld, int lane, int &n_sweeps) {
     const int npairs = n >> 1;
     const int rpl = (n + L - 1) / L;                    // rows per lane (<= RPL)
     const int k = lane / L, sub = lane - k * L;
     const bool on = k < npairs;
     const int r0 = sub * rpl, cnt = on ? max(0, min(n, r0 + rpl) - r0) : 0;
     for (int sweep = 0; sweep < 40; ++sweep) {
+        ++n_sweeps;
         bool rotated = false;
         for (int s = 0; s < n - 1; ++s) {
             int p = 0, q = 1;
             if (on) rr_pair(n, s, k, p, q);
-            double *ap = A + p * n + r0, *aq = A + q * n + r0, *vp = V + p * n + r0, *vq = V + q * n + r0;
-            double x[RPL], y[RPL];
+            double *ap = A + p * ld + r0, *aq = A + q * ld + r0, *vp = V + p * ld + r0, *vq = V + q * ld + r0;
+            // the V columns are fetched with the A columns: their LDS latency then hides under the dot products and
+            // the rotation math instead of starting a second round trip once the rotation is known
+            double x[RPL], y[RPL], vx[RPL], vy[RPL];
 #pragma unroll
             for (int i = 0; i < RPL; ++i) {
                 const bool in = i < cnt;
                 x[i] = in ? ap[i] : 0.0;
                 y[i] = in ? aq[i] : 0.0;
+                vx[i] = in ? vp[i] : 0.0;
+                vy[i] = in ? vq[i] : 0.0;
             }
             double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
             for (int i = 0; i < RPL; ++i) { al = fma(x[i], x[i], al); be = fma(y[i], y[i], be); ga = fma(x[i], y[i], ga); }
-#pragma unroll
-            for (int off = L >> 1; off > 0; off >>= 1) {
-                al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
-            }
+            group_sum3<L>(al, be, ga);
             // rotate when |ga| > 1e-15 sqrt(al be)  (compared squared: no square root on the test)
             const bool rot = on && (ga * ga > 1e-30 * (al * be)) && (ga != 0.0);
+            // a pair already orthogonal to 1e-7 is orthogonal to ~1e-14 after its rotation (quadratic convergence)
+            rotated = rotated || (rot && (ga * ga > 1e-14 * (al * be)));
             if (__any(rot)) {
                 // Rutishauser's stable formulas; reciprocal / square roots by Newton from the hardware
                 // seeds: the rotation only has to be orthogonal to working precision
@@ -89,13 +115,6 @@ __device__ void jacobi_svd_t(double *A, double *V, int n, int lane) {
                 const double tt = p2s_rcp(fabs(zeta) + p2s_sqrt(fma(zeta, zeta, 1.0)));
                 const double t = (zeta >= 0.0) ? tt : -tt;
                 const double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
-                double vx[RPL], vy[RPL];
-#pragma unroll
-                for (int i = 0; i < RPL; ++i) {
-                    const bool in = rot && i < cnt;
-                    vx[i] = in ? vp[i] : 0.0;
-                    vy[i] = in ? vq[i] : 0.0;
-                }
 #pragma unroll
                 for (int i = 0; i < RPL; ++i) {
                     if (rot && i < cnt) {
@@ -104,26 +123,26 @@ __device__ void jacobi_svd_t(double *A, double *V, int n, int lane) {
                     }
                 }
             }
-            rotated = rotated || rot;
             lds_fence();
         }
-        if (!__any(rotated)) break;
+        if (!__any(rotated)) break;          // no pair was further than 1e-7 from orthogonal in this sweep: done
     }
 }
 
 // Streaming form for wide columns (n > 32: more than 8 rows per lane would not fit the register file).
-__device__ void jacobi_svd_wide(double *A, double *V, int n, int lane, int L) {
+__device__ void jacobi_svd_wide(double *A, double *V, int n, int ld, int lane, int L, int &n_sweeps) {
     const int npairs = n >> 1;
     const int rpl = (n + L - 1) / L;
     const int k = lane / L, sub = lane - k * L;
     const bool on = k < npairs;
     const int r0 = sub * rpl, r1 = min(n, r0 + rpl);
     for (int sweep = 0; sweep < 40; ++sweep) {
+        ++n_sweeps;
         bool rotated = false;
         for (int s = 0; s < n - 1; ++s) {
             int p = 0, q = 1;
             if (on) rr_pair(n, s, k, p, q);
-            double *ap = A + p * n, *aq = A + q * n, *vp = V + p * n, *vq = V + q * n;
+            double *ap = A + p * ld, *aq = A + q * ld, *vp = V + p * ld, *vq = V + q * ld;
             double al = 0.0, be = 0.0, ga = 0.0;
             if (on) {
 #pragma unroll 4
@@ -136,6 +155,7 @@ __device__ void jacobi_svd_wide(double *A, double *V, int n, int lane, int L) {
                 al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
             }
             const bool rot = on && (fabs(ga) > 1e-15 * sqrt(al * be)) && (ga != 0.0);
+            rotated = rotated || (rot && (fabs(ga) > 1e-7 * sqrt(al * be)));
             if (rot) {
                 const double zeta = (be - al) / (2.0 * ga);
                 const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -148,29 +168,28 @@ __device__ void jacobi_svd_wide(double *A, double *V, int n, int lane, int L) {
                     vp[r] = c * vx - sn * vy; vq[r] = sn * vx + c * vy;
                 }
             }
-            rotated = rotated || rot;
             lds_fence();
         }
         if (!__any(rotated)) break;
     }
 }
 
-__device__ void jacobi_svd(double *A, double *V, int n, int lane) {
+__device__ void jacobi_svd(double *A, double *V, int n, int ld, int lane, int &n_sweeps) {
     const int npairs = n >> 1;
     int L = 1;
     while ((L << 1) * npairs <= 64) L <<= 1;            // lanes per column pair (power of two)
     const int rpl = (n + L - 1) / L;
     // (L, rows per lane) for even n: n <= 4 -> 32, n <= 8 -> 16, n <= 16 -> 8, n <= 32 -> 4, else 2
-    if (L == 32) jacobi_svd_t<1, 32>(A, V, n, lane);
-    else if (L == 16) jacobi_svd_t<1, 16>(A, V, n, lane);
-    else if (L == 8) jacobi_svd_t<2, 8>(A, V, n, lane);
-    else if (L == 4) jacobi_svd_t<8, 4>(A, V, n, lane);
-    else jacobi_svd_wide(A, V, n, lane, L);
+    if (L == 32) jacobi_svd_t<1, 32>(A, V, n, ld, lane, n_sweeps);
+    else if (L == 16) jacobi_svd_t<1, 16>(A, V, n, ld, lane, n_sweeps);
+    else if (L == 8) jacobi_svd_t<2, 8>(A, V, n, ld, lane, n_sweeps);
+    else if (L == 4) jacobi_svd_t<8, 4>(A, V, n, ld, lane, n_sweeps);
+    else jacobi_svd_wide(A, V, n, ld, lane, L, n_sweeps);
 }
 
 }  // namespace
 
-// LDS (doubles): A[n*n] V[n*n] Y[n*n] X[n*n] wts[n] ; ints: view[n].  The constant matrix W of matchSVT
+// LDS (doubles): A, V, Y, X of n x (n+1) each, wts[n] ; ints: view[n].  The constant matrix W of matchSVT
 // (read twice per element per iteration) lives in the frame's slab of the output buffer in HBM/L2 until
 // the result overwrites it: one matrix less in LDS lets a fourth frame share the CU.
 // the ray chunk aliases A, V, Y while the affinity is being accumulated
@@ -178,11 +197,15 @@ template <typename T>
 __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_max = a.Nmax;                       // even
+    // every LDS matrix has an odd leading dimension (n + 1): with 32 doubles per column the 16 column pairs of a
+    // Jacobi step (and the 32 rows read side by side in the products) all started in the same bank -- a 16-way
+    // conflict on every access, which is where most of the step's ~3 400 cycles went
+    const int mat = n_max * (n_max + 1);
     double *A = reinterpret_cast<double *>(smem);
-    double *V = A + n_max * n_max;
-    double *Y = V + n_max * n_max;
-    double *X = Y + n_max * n_max;
-    double *wts = X + n_max * n_max;
+    double *V = A + mat;
+    double *Y = V + mat;
+    double *X = Y + mat;
+    double *wts = X + mat;
     int *view = reinterpret_cast<int *>(wts + n_max);
     double *rays = A;                               // [person][joint in chunk][7]
     const int lane = threadIdx.x;
@@ -201,7 +224,8 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     }
     N = min(N, n_max);
     const int n = max(2, (N + 1) & ~1);             // even working size (zero padding)
-    for (int i = lane; i < n * n; i += 64) X[i] = 0.0;
+    const int ld = n + 1;                           // leading dimension of the LDS matrices
+    for (int i = lane; i < n * ld; i += 64) X[i] = 0.0;
     for (int i = N + lane; i < n; i += 64) view[i] = -1 - i;   // padding rows: each its own "view"
     for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
     lds_fence();
@@ -210,6 +234,10 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
 
     const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
     const int n_pairs = N * (N - 1) / 2;
+    const bool trace = a.debug_mode == 7;
+    uint64_t t_start = 0, t_aff = 0, t_prod = 0, t_svd = 0, t_upd = 0;
+    int n_sweeps = 0, n_iter = 0;
+    if (trace) t_start = __builtin_amdgcn_s_memtime();
 
     // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
     int Kc = (3 * n_max * n_max) / (7 * N);
@@ -257,7 +285,7 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
                 num = fma(fabs(prod), lk, num);
                 den += lk;
             }
-            X[ii * n + l] += num;
+            X[ii * ld + l] += num;
             W[ii * n + l] += den;
         }
         lds_fence();
@@ -270,21 +298,24 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
         if (i >= l) continue;
         double aff = 0.0;
         if (i < N && l < N && view[i] != view[l]) {
-            double d = X[i * n + l] / (1e-5 + W[i * n + l]);
+            double d = X[i * ld + l] / (1e-5 + W[i * n + l]);
             d = d > thr ? thr : d;                           // NaN stays NaN like the reference's comparison
             aff = 1.0 - d / thr;
         }
-        X[i * n + l] = aff; X[l * n + i] = aff;
+        X[i * ld + l] = aff; X[l * ld + i] = aff;
         W[i * n + l] = a.w_sparse - aff; W[l * n + i] = a.w_sparse - aff;
     }
-    for (int i = lane; i < n; i += 64) { X[i * n + i] = 0.0; W[i * n + i] = a.w_sparse; }
-    for (int i = lane; i < n * n; i += 64) Y[i] = 0.0;
+    for (int i = lane; i < n; i += 64) { X[i * ld + i] = 0.0; W[i * n + i] = a.w_sparse; }
+    for (int i = lane; i < n * ld; i += 64) Y[i] = 0.0;
     lds_fence();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
+    if (trace) t_aff = __builtin_amdgcn_s_memtime() - t_start;
     // ---- matchSVT (:477-505) --------------------------------------------------------------
     double mu = 64.0;
     for (int iter = 0; iter < a.max_iter; ++iter) {
+        uint64_t tt0 = 0;
+        if (trace) { tt0 = __builtin_amdgcn_s_memtime(); ++n_iter; }
         // SVT input B = X + Y/mu (:480), column-major for the column rotations.
         // First iteration: A = B, V = I.  Later iterations warm-start from the previous right singular
         // vectors: B changes little from one ADMM iteration to the next, so A = B . V_prev already has
@@ -292,8 +323,8 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
         if (iter == 0) {
             for (int i = lane; i < n * n; i += 64) {
                 const int r = i / n, c = i - r * n;
-                A[c * n + r] = X[i] + Y[i] * 1.0 / mu;
-                V[i] = (r == c) ? 1.0 : 0.0;
+                A[c * ld + r] = X[r * ld + c] + Y[r * ld + c] * 1.0 / mu;
+                V[c * ld + r] = (r == c) ? 1.0 : 0.0;
             }
         } else {
             const int lpr = max(1, 64 / n);                   // lanes per matrix row
@@ -307,22 +338,24 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
                 const int j0 = part * cpl + cb;
                 const int nj = on ? max(0, min(min(16, cpl - cb), n - j0)) : 0;
                 for (int kk = 0; kk < n; ++kk) {
-                    const double bk = X[row * n + kk] + Y[row * n + kk] * 1.0 / mu;   // B[row][kk]
+                    const double bk = X[row * ld + kk] + Y[row * ld + kk] * 1.0 / mu;   // B[row][kk]
 #pragma unroll
                     for (int jj = 0; jj < 16; ++jj)
-                        if (jj < nj) acc[jj] = fma(bk, V[(j0 + jj) * n + kk], acc[jj]);
+                        if (jj < nj) acc[jj] = fma(bk, V[(j0 + jj) * ld + kk], acc[jj]);
                 }
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj)
-                    if (jj < nj) A[(j0 + jj) * n + row] = acc[jj];
+                    if (jj < nj) A[(j0 + jj) * ld + row] = acc[jj];
             }
         }
         lds_fence();
-        jacobi_svd(A, V, n, lane);
+        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_prod += t - tt0; tt0 = t; }
+        jacobi_svd(A, V, n, ld, lane, n_sweeps);
+        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_svd += t - tt0; tt0 = t; }
         const double tsv = a.w_rank / mu;
         for (int j = lane; j < n; j += 64) {
             double s2 = 0.0;
-            for (int r = 0; r < n; ++r) s2 = fma(A[j * n + r], A[j * n + r], s2);
+            for (int r = 0; r < n; ++r) s2 = fma(A[j * ld + r], A[j * ld + r], s2);
             const double sg = sqrt(s2);
             wts[j] = (sg > tsv) ? (sg - tsv) / sg : 0.0;
         }
@@ -337,12 +370,12 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
             double q_il = 0.0, q_li = 0.0;                    // SVT (:443-445): U diag(max(s-t,0)) Vt
             for (int j = 0; j < n; ++j) {
                 const double w = wts[j];
-                q_il = fma(w * A[j * n + i], V[j * n + l], q_il);
-                q_li = fma(w * A[j * n + l], V[j * n + i], q_li);
+                q_il = fma(w * A[j * ld + i], V[j * ld + l], q_il);
+                q_li = fma(w * A[j * ld + l], V[j * ld + i], q_li);
             }
             const bool same_view = view[i] == view[l];
-            double x_il = q_il - (W[i * n + l] + Y[i * n + l]) / mu;   // :482
-            double x_li = q_li - (W[l * n + i] + Y[l * n + i]) / mu;
+            double x_il = q_il - (W[i * n + l] + Y[i * ld + l]) / mu;   // :482
+            double x_li = q_li - (W[l * n + i] + Y[l * ld + i]) / mu;
             if (same_view) { x_il = 0.0; x_li = 0.0; }        // :485-487
             if (i == l) { x_il = 1.0; x_li = 1.0; }           // :490
             x_il = x_il < 0.0 ? 0.0 : x_il; x_il = x_il > 1.0 ? 1.0 : x_il;   // :491-492
@@ -350,18 +383,19 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
             const double cc = (same_view && i != l) ? 0.0 : 1.0;              // :495
             x_il *= cc; x_li *= cc;
             const double sym = (x_il + x_li) / 2;             // :496
-            const double old_il = X[i * n + l], old_li = X[l * n + i];
-            Y[i * n + l] = Y[i * n + l] + mu * (sym - q_il);  // :497
+            const double old_il = X[i * ld + l], old_li = X[l * ld + i];
+            Y[i * ld + l] = Y[i * ld + l] + mu * (sym - q_il);  // :497
             pres2 += (sym - q_il) * (sym - q_il);
             dres2 += (sym - old_il) * (sym - old_il);
             if (i != l) {
-                Y[l * n + i] = Y[l * n + i] + mu * (sym - q_li);
+                Y[l * ld + i] = Y[l * ld + i] + mu * (sym - q_li);
                 pres2 += (sym - q_li) * (sym - q_li);
                 dres2 += (sym - old_li) * (sym - old_li);
             }
-            X[i * n + l] = sym; X[l * n + i] = sym;
+            X[i * ld + l] = sym; X[l * ld + i] = sym;
         }
         lds_fence();
+        if (trace) t_upd += __builtin_amdgcn_s_memtime() - tt0;
         const double pRes = sqrt(wave_sum(pres2)) / (double)N;          // :500
         const double dRes = mu * sqrt(wave_sum(dres2)) / (double)N;     // :501
         if (pRes < a.tol && dRes < a.tol) break;                        // :502
@@ -373,13 +407,20 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (int pr = lane; pr < N * N; pr += 64) {
         const int i = pr / N, l = pr - i * N;
-        const double v = X[i * n + l];
+        const double v = X[i * ld + l];
         out[i * n_max + l] = (v < a.min_affinity) ? 0.0 : v;
+    }
+    if (trace) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (lane == 0) {
+            out[0] = (double)(__builtin_amdgcn_s_memtime() - t_start); out[1] = (double)t_aff; out[2] = (double)t_prod;
+            out[3] = (double)t_svd; out[4] = (double)t_upd; out[5] = (double)n_sweeps; out[6] = (double)n_iter; out[7] = (double)N;
+        }
     }
 }
 
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
-    const size_t lds = (size_t)(4 * a.Nmax * a.Nmax + a.Nmax) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
+    const size_t lds = (size_t)(4 * a.Nmax * (a.Nmax + 1) + a.Nmax) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
     hipError_t e;
     if (dtype == P2S_F32) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_assoc_kernel<float>),

@@ -61,6 +61,7 @@ struct P2sAssocArgs {
     const P2sCam *cams;
     int64_t n_frames;
     int32_t C, Kj, Nmax, max_iter;
+    int32_t debug_mode;         // diagnostics only: 7 = per-frame phase timeline instead of the result (exp/assoc_trace.py)
     double recon_thr, min_affinity, w_rank, tol, w_sparse;
 };
 
