@@ -18,6 +18,7 @@
 // ~10^7 fp64 flops on ~10 KB of input: compute/latency bound, LDS resident, no MFMA (the matrices
 // are 32 x 32 and every step is data dependent).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include <math.h>
 
@@ -33,10 +34,42 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// NW waves work on one frame: NW = 1 needs only wave-local ordering, NW = 2 a workgroup barrier.
+template <int NW>
 __device__ __forceinline__ void lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// OR / sum over the whole workgroup (scratch: 2 * NW doubles of LDS, reused)
+template <int NW>
+__device__ __forceinline__ bool block_any(bool v, double *scratch, int tid) {
+    const bool w = __any(v);
+    if constexpr (NW == 1) return w;
+    if ((tid & 63) == 0) scratch[tid >> 6] = w ? 1.0 : 0.0;
+    __syncthreads();
+    bool r = false;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r = r || (scratch[i] != 0.0);
+    __syncthreads();
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double *scratch, int tid) {
+    v = wave_sum(v);
+    if constexpr (NW == 1) return v;
+    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r += scratch[i];
+    __syncthreads();
+    return r;
 }
 
 // Sum over the L consecutive lanes of a column pair with DPP moves (L = 2, 4, 8, 16): quad permutes for the first
@@ -75,8 +108,8 @@ __device__ __forceinline__ void rr_pair(int n, int s, int k, int &p, int &q) {
 // which case A must already be (input matrix) . V).
 // RPL = rows per lane (compile time): the RPL column elements a lane owns are read with one batch of
 // LDS loads and held in registers, so a round-robin step costs two LDS round trips instead of 4*RPL.
-template <int RPL, int L>
-__device__ void jacobi_svd_t(double *A, double *V, int n, int ld, int lane, int &n_sweeps) {
+template <int RPL, int L, int NW>
+__device__ void jacobi_svd_t(double *A, double *V, int n, int ld, int lane, int &n_sweeps, double *scratch) {
     const int npairs = n >> 1;
     const int rpl = (n + L - 1) / L;                    // rows per lane (<= RPL)
     const int k = lane / L, sub = lane - k * L;
@@ -123,14 +156,15 @@ __device__ void jacobi_svd_t(double *A, double *V, int n, int ld, int lane, int 
                     }
                 }
             }
-            lds_fence();
+            lds_fence<NW>();
         }
-        if (!__any(rotated)) break;          // no pair was further than 1e-7 from orthogonal in this sweep: done
+        if (!block_any<NW>(rotated, scratch, lane)) break;   // no pair was further than 1e-7 from orthogonal in this sweep: done
     }
 }
 
 // Streaming form for wide columns (n > 32: more than 8 rows per lane would not fit the register file).
-__device__ void jacobi_svd_wide(double *A, double *V, int n, int ld, int lane, int L, int &n_sweeps) {
+template <int NW>
+__device__ void jacobi_svd_wide(double *A, double *V, int n, int ld, int lane, int L, int &n_sweeps, double *scratch) {
     const int npairs = n >> 1;
     const int rpl = (n + L - 1) / L;
     const int k = lane / L, sub = lane - k * L;
@@ -168,23 +202,26 @@ __device__ void jacobi_svd_wide(double *A, double *V, int n, int ld, int lane, i
                     vp[r] = c * vx - sn * vy; vq[r] = sn * vx + c * vy;
                 }
             }
-            lds_fence();
+            lds_fence<NW>();
         }
-        if (!__any(rotated)) break;
+        if (!block_any<NW>(rotated, scratch, lane)) break;
     }
 }
 
-__device__ void jacobi_svd(double *A, double *V, int n, int ld, int lane, int &n_sweeps) {
+template <int NW>
+__device__ void jacobi_svd(double *A, double *V, int n, int ld, int lane, int &n_sweeps, double *scratch) {
     const int npairs = n >> 1;
     int L = 1;
-    while ((L << 1) * npairs <= 64) L <<= 1;            // lanes per column pair (power of two)
+    while ((L << 1) * npairs <= 64 * NW && L < 32) L <<= 1;   // lanes per column pair (power of two, within a wave)
+    // one wave:  n <= 4 -> 32, n <= 8 -> 16, n <= 16 -> 8, n <= 32 -> 4, else 2
+    // two waves: n <= 8 -> 32, n <= 16 -> 16, n <= 32 -> 8, n <= 64 -> 4
     const int rpl = (n + L - 1) / L;
-    // (L, rows per lane) for even n: n <= 4 -> 32, n <= 8 -> 16, n <= 16 -> 8, n <= 32 -> 4, else 2
-    if (L == 32) jacobi_svd_t<1, 32>(A, V, n, ld, lane, n_sweeps);
-    else if (L == 16) jacobi_svd_t<1, 16>(A, V, n, ld, lane, n_sweeps);
-    else if (L == 8) jacobi_svd_t<2, 8>(A, V, n, ld, lane, n_sweeps);
-    else if (L == 4) jacobi_svd_t<8, 4>(A, V, n, ld, lane, n_sweeps);
-    else jacobi_svd_wide(A, V, n, ld, lane, L, n_sweeps);
+    if (L == 32) jacobi_svd_t<1, 32, NW>(A, V, n, ld, lane, n_sweeps, scratch);
+    else if (L == 16) jacobi_svd_t<1, 16, NW>(A, V, n, ld, lane, n_sweeps, scratch);
+    else if (L == 8 && rpl <= 2) jacobi_svd_t<2, 8, NW>(A, V, n, ld, lane, n_sweeps, scratch);
+    else if (L == 8 && rpl <= 4) jacobi_svd_t<4, 8, NW>(A, V, n, ld, lane, n_sweeps, scratch);
+    else if (L == 4 && rpl <= 8) jacobi_svd_t<8, 4, NW>(A, V, n, ld, lane, n_sweeps, scratch);
+    else jacobi_svd_wide<NW>(A, V, n, ld, lane, L, n_sweeps, scratch);
 }
 
 }  // namespace
@@ -193,8 +230,9 @@ __device__ void jacobi_svd(double *A, double *V, int n, int ld, int lane, int &n
 // (read twice per element per iteration) lives in the frame's slab of the output buffer in HBM/L2 until
 // the result overwrites it: one matrix less in LDS lets a fourth frame share the CU.
 // the ray chunk aliases A, V, Y while the affinity is being accumulated
-template <typename T>
-__global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
+template <typename T, int NW>
+__global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a) {
+    constexpr int NT = 64 * NW;                     // threads working on this frame
     extern __shared__ __align__(16) unsigned char smem[];
     const int n_max = a.Nmax;                       // even
     // every LDS matrix has an odd leading dimension (n + 1): with 32 doubles per column the 16 column pairs of a
@@ -206,9 +244,10 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     double *Y = V + mat;
     double *X = Y + mat;
     double *wts = X + mat;
-    int *view = reinterpret_cast<int *>(wts + n_max);
+    double *scratch = wts + n_max;                  // 4 doubles for the workgroup reductions
+    int *view = reinterpret_cast<int *>(scratch + 4);
     double *rays = A;                               // [person][joint in chunk][7]
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;                   // 0 .. NT-1
     const int64_t f = blockIdx.x;
     const int C = a.C, Kj = a.Kj;
     double *out = a.affinity + f * (int64_t)n_max * n_max;
@@ -218,17 +257,17 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     int N = 0;
     for (int c = 0; c < C; ++c) {
         const int pc = a.n_persons[f * C + c];
-        for (int i = lane; i < pc; i += 64)
+        for (int i = lane; i < pc; i += NT)
             if (N + i < n_max) view[N + i] = c;
         N += pc;
     }
     N = min(N, n_max);
     const int n = max(2, (N + 1) & ~1);             // even working size (zero padding)
     const int ld = n + 1;                           // leading dimension of the LDS matrices
-    for (int i = lane; i < n * ld; i += 64) X[i] = 0.0;
-    for (int i = N + lane; i < n; i += 64) view[i] = -1 - i;   // padding rows: each its own "view"
-    for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
-    lds_fence();
+    for (int i = lane; i < n * ld; i += NT) X[i] = 0.0;
+    for (int i = N + lane; i < n; i += NT) view[i] = -1 - i;   // padding rows: each its own "view"
+    for (int i = lane; i < n_max * n_max; i += NT) out[i] = 0.0;
+    lds_fence<NW>();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // W (global) is read back by other lanes of this wave
     if (N == 0) return;
 
@@ -244,7 +283,7 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
     Kc = max(1, min(Kc, Kj));
     for (int j0 = 0; j0 < Kj; j0 += Kc) {
         const int kc = min(Kc, Kj - j0);
-        for (int it = lane; it < N * kc; it += 64) {          // compute_rays (:293-314)
+        for (int it = lane; it < N * kc; it += NT) {          // compute_rays (:293-314)
             const int i = it / kc, j = it - i * kc;
             const P2sCam &cam = a.cams[view[i]];
             const T *o = kp + ((int64_t)i * Kj + j0 + j) * 3;
@@ -267,8 +306,8 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
             double *r = rays + ((size_t)i * kc + j) * 7;
             r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1; r[5] = m2; r[6] = lk;
         }
-        lds_fence();
-        for (int pr = lane; pr < n_pairs; pr += 64) {         // compute_affinity (:383-394)
+        lds_fence<NW>();
+        for (int pr = lane; pr < n_pairs; pr += NT) {         // compute_affinity (:383-394)
             // pair index -> (i, l), i < l
             int i = (int)((1.0 + sqrt(1.0 + 8.0 * (double)pr)) * 0.5);
             while (i * (i - 1) / 2 > pr) --i;
@@ -288,12 +327,12 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
             X[ii * ld + l] += num;
             W[ii * n + l] += den;
         }
-        lds_fence();
+        lds_fence<NW>();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     // distance -> affinity (:397-406), circular constraint (:794-795), matchSVT initialisation (:467-475)
     const double thr = a.recon_thr;
-    for (int pr = lane; pr < n * n; pr += 64) {
+    for (int pr = lane; pr < n * n; pr += NT) {
         const int i = pr / n, l = pr - i * n;
         if (i >= l) continue;
         double aff = 0.0;
@@ -305,9 +344,9 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
         X[i * ld + l] = aff; X[l * ld + i] = aff;
         W[i * n + l] = a.w_sparse - aff; W[l * n + i] = a.w_sparse - aff;
     }
-    for (int i = lane; i < n; i += 64) { X[i * ld + i] = 0.0; W[i * n + i] = a.w_sparse; }
-    for (int i = lane; i < n * ld; i += 64) Y[i] = 0.0;
-    lds_fence();
+    for (int i = lane; i < n; i += NT) { X[i * ld + i] = 0.0; W[i * n + i] = a.w_sparse; }
+    for (int i = lane; i < n * ld; i += NT) Y[i] = 0.0;
+    lds_fence<NW>();
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
     if (trace) t_aff = __builtin_amdgcn_s_memtime() - t_start;
@@ -321,13 +360,13 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
         // vectors: B changes little from one ADMM iteration to the next, so A = B . V_prev already has
         // nearly orthogonal columns and the Jacobi iteration needs ~2 sweeps instead of ~8.
         if (iter == 0) {
-            for (int i = lane; i < n * n; i += 64) {
+            for (int i = lane; i < n * n; i += NT) {
                 const int r = i / n, c = i - r * n;
                 A[c * ld + r] = X[r * ld + c] + Y[r * ld + c] * 1.0 / mu;
                 V[c * ld + r] = (r == c) ? 1.0 : 0.0;
             }
         } else {
-            const int lpr = max(1, 64 / n);                   // lanes per matrix row
+            const int lpr = max(1, NT / n);                   // lanes per matrix row
             const int row = lane % n, part = lane / n;
             const int cpl = (n + lpr - 1) / lpr;              // columns per lane
             const bool on = part < lpr;
@@ -348,20 +387,20 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
                     if (jj < nj) A[(j0 + jj) * ld + row] = acc[jj];
             }
         }
-        lds_fence();
+        lds_fence<NW>();
         if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_prod += t - tt0; tt0 = t; }
-        jacobi_svd(A, V, n, ld, lane, n_sweeps);
+        jacobi_svd<NW>(A, V, n, ld, lane, n_sweeps, scratch);
         if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_svd += t - tt0; tt0 = t; }
         const double tsv = a.w_rank / mu;
-        for (int j = lane; j < n; j += 64) {
+        for (int j = lane; j < n; j += NT) {
             double s2 = 0.0;
             for (int r = 0; r < n; ++r) s2 = fma(A[j * ld + r], A[j * ld + r], s2);
             const double sg = sqrt(s2);
             wts[j] = (sg > tsv) ? (sg - tsv) / sg : 0.0;
         }
-        lds_fence();
+        lds_fence<NW>();
         double pres2 = 0.0, dres2 = 0.0;
-        for (int pr = lane; pr < n * (n + 1) / 2; pr += 64) {
+        for (int pr = lane; pr < n * (n + 1) / 2; pr += NT) {
             int l = (int)((sqrt(1.0 + 8.0 * (double)pr) - 1.0) * 0.5);
             while (l * (l + 1) / 2 > pr) --l;
             while ((l + 1) * (l + 2) / 2 <= pr) ++l;
@@ -394,23 +433,25 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
             }
             X[i * ld + l] = sym; X[l * ld + i] = sym;
         }
-        lds_fence();
+        lds_fence<NW>();
         if (trace) t_upd += __builtin_amdgcn_s_memtime() - tt0;
-        const double pRes = sqrt(wave_sum(pres2)) / (double)N;          // :500
-        const double dRes = mu * sqrt(wave_sum(dres2)) / (double)N;     // :501
+        const double pRes = sqrt(block_sum<NW>(pres2, scratch, lane)) / (double)N;          // :500
+        const double dRes = mu * sqrt(block_sum<NW>(dres2, scratch, lane)) / (double)N;     // :501
         if (pRes < a.tol && dRes < a.tol) break;                        // :502
         if (pRes > 10 * dRes) mu = 2 * mu;                              // :504
         else if (dRes > 10 * pRes) mu = mu / 2;                         // :505
     }
     // ---- min_affinity cut (:800) and store (the slab held W until now) ---------------------------
-    for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
+    for (int i = lane; i < n_max * n_max; i += NT) out[i] = 0.0;
+    lds_fence<NW>();                                 // the zeros of one wave must not land on the values of the other
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (int pr = lane; pr < N * N; pr += 64) {
+    for (int pr = lane; pr < N * N; pr += NT) {
         const int i = pr / N, l = pr - i * N;
         const double v = X[i * ld + l];
         out[i * n_max + l] = (v < a.min_affinity) ? 0.0 : v;
     }
     if (trace) {
+        lds_fence<NW>();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (lane == 0) {
             out[0] = (double)(__builtin_amdgcn_s_memtime() - t_start); out[1] = (double)t_aff; out[2] = (double)t_prod;
@@ -420,18 +461,19 @@ __global__ void __launch_bounds__(64) p2s_assoc_kernel(const P2sAssocArgs a) {
 }
 
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
-    const size_t lds = (size_t)(4 * a.Nmax * (a.Nmax + 1) + a.Nmax) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
+    const size_t lds = (size_t)(4 * a.Nmax * (a.Nmax + 1) + a.Nmax + 4) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
+    // two waves per frame from 18 detections up: the Jacobi step is a chain of dependent operations, and with
+    // ~34 KB of LDS per frame only 4 frames fit a CU -- a second wave per frame gives every SIMD two waves to
+    // interleave and halves the rows a lane rotates
+    const bool two = a.Nmax > 16 && !getenv("P2S_ASSOC_ONE_WAVE");
     hipError_t e;
-    if (dtype == P2S_F32) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_assoc_kernel<float>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((p2s_assoc_kernel<float>), dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_assoc_kernel<double>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((p2s_assoc_kernel<double>), dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
-    }
-    return hipGetLastError();
+    auto go = [&](auto kern, int threads) -> hipError_t {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(threads), lds, s, a);
+        return hipGetLastError();
+    };
+    if (dtype == P2S_F32) e = two ? go(&p2s_assoc_kernel<float, 2>, 128) : go(&p2s_assoc_kernel<float, 1>, 64);
+    else e = two ? go(&p2s_assoc_kernel<double, 2>, 128) : go(&p2s_assoc_kernel<double, 1>, 64);
+    return e;
 }
