@@ -59,25 +59,33 @@ def sharded_triangulate(compute, xyl):
     Returns the full-size (Q [F][Pn][K][3], err, n_excl, mask) on every rank.
     """
     rank, world = dist_info()
-    F, Pn, K = xyl.shape[0], xyl.shape[1], xyl.shape[3]
+    F = xyl.shape[0]
     if world == 1 and not os.environ.get('P2S_FORCE_COLLECTIVE'):   # the variable: tests of the RCCL path on one GPU
         return compute(xyl)
+    lo, hi = shard_bounds(F, rank, world)
+    return gather_results(compute(xyl[lo:hi]), F, xyl.shape[1], xyl.shape[3])
+
+
+def gather_results(local, F, Pn, K):
+    """The single collective of the path: every rank contributes the results of its contiguous frame block
+    (``shard_bounds``) and receives the whole trajectory.  local = (Q [n][Pn][K][3], err, n_excl, mask)."""
+    rank, world = dist_info()
+    Q, err, nex, mask = local
+    if world == 1 and not os.environ.get('P2S_FORCE_COLLECTIVE'):
+        return Q, err, nex, mask
     import torch
     import torch.distributed as dist
     lo, hi = shard_bounds(F, rank, world)
-    Q, err, nex, mask = compute(xyl[lo:hi])
     nb_max = (shard_bounds(F, 0, world)[1] - shard_bounds(F, 0, world)[0]) * Pn
     per_unit = 24 + 4 + 4 + 1
-    local = np.zeros(nb_max * K * per_unit, dtype=np.uint8)
-    packed = pack_results(Q, err, nex, mask)
-    # sections are sized for the local block count: repack into the padded layout
+    local_buf = np.zeros(nb_max * K * per_unit, dtype=np.uint8)
     nb = (hi - lo) * Pn
-    padded = pack_results(_pad(Q.reshape(nb, K, 3), nb_max), _pad(err.reshape(nb, K), nb_max),
-                          _pad(nex.reshape(nb, K), nb_max), _pad(mask.reshape(nb, K), nb_max)) if nb != nb_max else packed
-    local[:] = padded
+    # sections are sized for the largest block: pad the local block to it
+    local_buf[:] = pack_results(_pad(np.asarray(Q).reshape(nb, K, 3), nb_max), _pad(np.asarray(err).reshape(nb, K), nb_max),
+                                _pad(np.asarray(nex).reshape(nb, K), nb_max), _pad(np.asarray(mask).reshape(nb, K), nb_max))
     backend = dist.get_backend()
     dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-    t_local = torch.from_numpy(local).to(dev)
+    t_local = torch.from_numpy(local_buf).to(dev)
     t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(t_all, t_local)          # the single collective of the path
     allbuf = t_all.cpu().numpy().reshape(world, -1)
@@ -92,6 +100,27 @@ def sharded_triangulate(compute, xyl):
     nf = np.concatenate([o[2] for o in outs]).reshape(F, Pn, K)
     mf = np.concatenate([o[3] for o in outs]).reshape(F, Pn, K)
     return Qf, ef, nf, mf
+
+
+def agree_max(value, error=None):
+    """max of an integer over the ranks, and every rank raises when any of them hit an error (so that a rank
+    that cannot read its share of the files does not leave the others waiting in a collective)."""
+    rank, world = dist_info()
+    if world == 1:
+        if error is not None:
+            raise error
+        return value
+    import torch
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    t = torch.tensor([int(value), 1 if error is not None else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[1].item()):
+        if error is not None:
+            raise error
+        raise RuntimeError('another rank failed while reading its share of the pose files')
+    return int(t[0].item())
 
 
 def _pad(a, n):

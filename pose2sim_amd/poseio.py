@@ -91,6 +91,22 @@ def max_persons_in_trial(batch, paths):
     return max(best, int(batch.counts.max(initial=0)))
 
 
+def max_persons_sharded(root, json_dirs, json_files_names, rank, world):
+    """max_persons_in_trial with the files dealt out over the ranks (every world-th file each) and one
+    all-reduce(max); an unreadable file raises on every rank."""
+    from . import parallel
+    from .ingest import JsonBatch
+    paths, _ = _trial_paths(root, json_dirs, json_files_names)
+    mine = paths[rank::world]
+    best, error = 0, None
+    try:
+        with JsonBatch(mine) as batch:
+            best = max_persons_in_trial(batch, mine)
+    except Exception as e:                                   # noqa: BLE001 -- re-raised on every rank below
+        error = e
+    return parallel.agree_max(best, error)
+
+
 def load_observations(root, json_dirs, maps, f_range, keypoints_ids, nb_persons, json_files_names=None,
                       count_all_persons=False):
     """extract_files_frame_f (triangulation.py:607-653) for every frame of f_range at once, through the native

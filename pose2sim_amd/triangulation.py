@@ -147,22 +147,27 @@ def triangulate_all(config_dict):
     if n_cams != len(P):
         raise Exception(f'Error: The number of cameras is not consistent: Found {len(P)} cameras in the calibration file, and {n_cams} cameras based on the number of pose folders.')
 
-    # ---- every frame at once: JSON -> packed tensor (native parser) -> HIP engine -------------------
+    # ---- JSON -> packed tensor (native parser) -> HIP engine.  One process: every frame at once.  Several
+    # ranks: each one reads, parses and triangulates only its contiguous block of frames (the ingest is the
+    # longest stage by far), then ONE all-gather reassembles the trajectory on every rank.
     maps = poseio.frame_file_map(json_files_names)
-    if multi_person:
-        xyl, nb_persons = poseio.load_observations(pose_dir, json_dirs_names, maps, f_range, keypoints_ids, 0,
+    rank, world = parallel.dist_info()
+    n_frames = max(0, f_range[1] - f_range[0])
+    lo, hi = parallel.shard_bounds(n_frames, rank, world)
+    my_range = (f_range[0] + lo, f_range[0] + hi)
+    if multi_person and world == 1:
+        xyl, nb_persons = poseio.load_observations(pose_dir, json_dirs_names, maps, my_range, keypoints_ids, 0,
                                                    json_files_names=json_files_names, count_all_persons=True)
     else:
         nb_persons = 1
-        xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, f_range, keypoints_ids, nb_persons)
+        if multi_person:                                   # the person count is a maximum over ALL files (:784)
+            nb_persons = poseio.max_persons_sharded(pose_dir, json_dirs_names, json_files_names, rank, world)
+        xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, my_range, keypoints_ids, nb_persons)
     engine = _make_engine()
     engine.set_calibration(P, calib_params if undistort_points else None)
     prm = engine.tri_params(error_threshold, likelihood_threshold, min_cameras, undistort_points, handle_LR_swap)
-
-    def compute(x):
-        return engine.triangulate(x, prm, keypoints_idx_swapped if handle_LR_swap else None)
-    Qk, ek, nk, mk = parallel.sharded_triangulate(compute, xyl)
-    rank, _ = parallel.dist_info()
+    local = engine.triangulate(xyl, prm, keypoints_idx_swapped if handle_LR_swap else None)
+    Qk, ek, nk, mk = parallel.gather_results(local, n_frames, nb_persons, keypoints_nb)
 
     Q_rows, e_rows, n_rows, m_rows = track_persons(Qk, ek, nk, mk, f_range, multi_person, max_distance_m, n_cams)
     index = range(*f_range)

@@ -69,3 +69,68 @@ def test_shard_bounds_cover_every_frame_once():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _trial_worker(rank, world, port, root, trial, multi):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import torch.distributed as dist
+    import e2e_common as ec
+    from pose2sim_amd import poseio, triangulation
+    from test_e2e_trc import OracleEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.chdir(root)
+    parsed = []
+    orig = poseio.load_observations
+
+    def spy(root_, dirs, maps, f_range, *a, **k):
+        parsed.append(tuple(f_range))
+        return orig(root_, dirs, maps, f_range, *a, **k)
+    poseio.load_observations = spy
+    triangulation._make_engine = lambda: OracleEngine()
+    cfg = ec.base_config(trial, multi)
+    cfg['project']['project_dir'] = trial
+    paths = triangulation.triangulate_all(cfg)
+    with open(os.path.join(root, f'rank{rank}.txt'), 'w') as fh:
+        fh.write(repr(parsed) + '\n' + repr([os.path.basename(p) for p in paths if p]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('multi', [False, True])
+def test_two_ranks_read_only_their_frames_and_write_the_same_trc(tmp_path, multi):
+    """triangulate_all under two gloo ranks: each rank parses only its block of frames (the ingest is sharded, not
+    just the kernels), the person count of multi-person mode is agreed with one all-reduce, and the .trc written
+    by rank 0 equals the single-process file byte for byte."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import e2e_common as ec
+    from pose2sim_amd import skeletons, synth, triangulation
+    from test_e2e_trc import OracleEngine
+    ids, names, swap = skeletons.keypoints('HALPE_26')
+    F = 23
+    wl = synth.make_config(F, 4, len(ids), 2 if multi else 1, seed=41, p_missing_cam=0.0)
+    sub = 'pose-associated' if multi else 'pose'
+    outs = {}
+    for mode in ('single', 'two'):
+        root = str(tmp_path / mode)
+        trial = ec.write_trial(root, 'trial', wl['cams'], ec.people_from_xyl(wl['xyl'], ids, 26), json_subdir=sub)
+        if mode == 'single':
+            cwd = os.getcwd()
+            os.chdir(root)
+            try:
+                orig = triangulation._make_engine
+                triangulation._make_engine = lambda: OracleEngine()
+                triangulation.triangulate_all(ec.base_config(trial, multi))
+            finally:
+                triangulation._make_engine = orig
+                os.chdir(cwd)
+        else:
+            mp.spawn(_trial_worker, args=(2, _free_port(), root, trial, multi), nprocs=2, join=True)
+        d = os.path.join(trial, 'pose-3d')
+        outs[mode] = {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.endswith('.trc')}
+    assert outs['single'] and outs['single'] == outs['two']
+    r0 = open(os.path.join(str(tmp_path / 'two'), 'rank0.txt')).read().split('\n')
+    r1 = open(os.path.join(str(tmp_path / 'two'), 'rank1.txt')).read().split('\n')
+    assert r0[0] == repr([(0, 12)]) and r1[0] == repr([(12, 23)])          # each rank parsed only its own block
