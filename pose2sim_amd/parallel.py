@@ -123,6 +123,18 @@ def agree_max(value, error=None):
     return int(t[0].item())
 
 
+def gather_lists(*lists):
+    """Concatenate per-rank Python lists in rank order on every rank (statistics for the recap lines)."""
+    rank, world = dist_info()
+    if world == 1:
+        return lists if len(lists) > 1 else lists[0]
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, [list(x) for x in lists])
+    out = tuple([v for part in parts for v in part[i]] for i in range(len(lists)))
+    return out if len(lists) > 1 else out[0]
+
+
 def _pad(a, n):
     if a.shape[0] == n:
         return a

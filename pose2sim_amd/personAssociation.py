@@ -285,12 +285,12 @@ def associate_all(config_dict):
         except Exception:
             raise ValueError(f'No json files found in {pose_dir} nor {poseSync_dir} subdirectories. Make sure you run Pose2Sim.poseEstimation() first.')
 
-    if not os.path.exists(poseTracked_dir):
-        os.mkdir(poseTracked_dir)
-    try:
-        [os.mkdir(os.path.join(poseTracked_dir, k)) for k in json_dirs_names]
-    except Exception:
-        pass
+    os.makedirs(poseTracked_dir, exist_ok=True)               # (several ranks may arrive here together)
+    for k in json_dirs_names:
+        try:
+            os.mkdir(os.path.join(poseTracked_dir, k))
+        except Exception:
+            pass
 
     f_range = [[0, max([len(j) for j in json_files_names])] if frame_range in ('all', 'auto', []) else frame_range][0]   # max, :736
     n_cams = len(json_dirs_names)
@@ -300,7 +300,12 @@ def associate_all(config_dict):
                     and {n_cams} cameras based on the number of pose folders.')
 
     maps = poseio.frame_file_map(json_files_names)
-    frames = range(*f_range)
+    # Frames are independent and every frame has its own output files: with several ranks (torch.distributed)
+    # each one reads, associates and rewrites only its contiguous block, and no result has to be exchanged.
+    from . import parallel
+    rank, world = parallel.dist_info()
+    lo, hi = parallel.shard_bounds(max(0, f_range[1] - f_range[0]), rank, world)
+    frames = range(f_range[0] + lo, f_range[0] + hi)
 
     if not multi_person:
         logging.info('\nSingle-person analysis selected.')
@@ -310,7 +315,9 @@ def associate_all(config_dict):
         frames_dst = [[os.path.join(poseTracked_dir, json_dirs_names[c], nm[c]) for c in range(n_cams)] for nm in names]
         error_min_tot, cameras_off_tot = _associate_single_person(config_dict, frames_src, frames_dst, n_cams,
                                                                   P_all, calib_params)
-        recap_tracking(config_dict, error_min_tot, cameras_off_tot)
+        error_min_tot, cameras_off_tot = parallel.gather_lists(error_min_tot, cameras_off_tot)   # recap over all frames
+        if rank == 0:
+            recap_tracking(config_dict, error_min_tot, cameras_off_tot)
         return
     logging.info('\nMulti-person analysis selected.')
 
@@ -334,6 +341,7 @@ def associate_all(config_dict):
     affinity = engine.associate(n_persons, kpts, prm)
 
     proposals_all = proposals_batch(affinity, n_persons, min_cameras_for_triangulation)        # host threads
-    rewrite_json_files_batch(dst_files, src_files, proposals_all, n_cams)         # every file of the trial, host threads
+    rewrite_json_files_batch(dst_files, src_files, proposals_all, n_cams)         # every file of this rank's block, host threads
 
-    recap_tracking(config_dict)
+    if rank == 0:
+        recap_tracking(config_dict)

@@ -134,3 +134,63 @@ def test_two_ranks_read_only_their_frames_and_write_the_same_trc(tmp_path, multi
     r0 = open(os.path.join(str(tmp_path / 'two'), 'rank0.txt')).read().split('\n')
     r1 = open(os.path.join(str(tmp_path / 'two'), 'rank1.txt')).read().split('\n')
     assert r0[0] == repr([(0, 12)]) and r1[0] == repr([(12, 23)])          # each rank parsed only its own block
+
+
+def _assoc_worker(rank, world, port, root, trial, multi, thr, min_cams):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import torch.distributed as dist
+    import e2e_common as ec
+    from pose2sim_amd import personAssociation as pa
+    from test_e2e_assoc import OracleAssocEngine, OracleSingleEngine
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.chdir(root)
+    pa._make_engine = (lambda: OracleAssocEngine()) if multi else (lambda: OracleSingleEngine())
+    cfg = ec.base_config(trial, multi, min_cameras_for_triangulation=min_cams)
+    cfg['personAssociation']['single_person']['reproj_error_threshold_association'] = thr
+    pa.associate_all(cfg)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('multi', [True, False])
+def test_two_ranks_associate_their_own_frames(golden_dir, tmp_path, multi):
+    """associate_all under two gloo ranks: every rank handles its block of frames and writes its own files; together
+    they are exactly the files the reference wrote (goldens of test_e2e_assoc.py)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import e2e_common as ec
+    if multi:
+        z = np.load(os.path.join(golden_dir, 'e2e_assoc.npz'))
+        pre, thr, min_cams = '', 20.0, 2
+    else:
+        z = np.load(os.path.join(golden_dir, 'e2e_single.npz'))
+        pre = 's4_'
+        thr, min_cams = float(z['s4_thr']), int(z['s4_min_cams'])
+    cams = ec.cams_from_arrays(z, prefix=pre)
+    n_persons = z[pre + 'n_persons']
+    F, C = n_persons.shape
+    frames, row = [], 0
+    for f in range(F):
+        per_cam = []
+        for c in range(C):
+            if multi and z['missing'][f, c]:
+                per_cam.append(None)
+                continue
+            n = int(n_persons[f, c])
+            per_cam.append([z[pre + 'kpts'][row + i].ravel() for i in range(n)])
+            row += n
+        frames.append(per_cam)
+    root = str(tmp_path / 'two')
+    trial = ec.write_trial(root, 'trial_assoc' if multi else 'trial_s4', cams, frames, json_subdir='pose')
+    mp.spawn(_assoc_worker, args=(2, _free_port(), root, trial, multi, thr, min_cams), nprocs=2, join=True)
+    got = {}
+    d = os.path.join(trial, 'pose-associated')
+    for cam in sorted(os.listdir(d)):
+        for fn in sorted(os.listdir(os.path.join(d, cam))):
+            got[f'{cam}/{fn}'] = open(os.path.join(d, cam, fn)).read()
+    want = {str(n): str(t) for n, t in zip(z[pre + 'names'], z[pre + 'texts'])}
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], k
