@@ -224,6 +224,19 @@ __device__ void jacobi_svd(double *A, double *V, int n, int ld, int lane, int &n
     else jacobi_svd_wide<NW>(A, V, n, ld, lane, L, n_sweeps, scratch);
 }
 
+// Two waves, n <= 32: at least 8 lanes per column pair, at most 4 rows per lane -- the light instantiations only
+// (the register-state kernel must stay under 168 VGPRs for 3 waves per SIMD).
+__device__ void jacobi_svd_small2(double *A, double *V, int n, int ld, int lane, int &n_sweeps, double *scratch) {
+    const int npairs = n >> 1;
+    int L = 1;
+    while ((L << 1) * npairs <= 128 && L < 32) L <<= 1;
+    const int rpl = (n + L - 1) / L;
+    if (L == 32) jacobi_svd_t<1, 32, 2>(A, V, n, ld, lane, n_sweeps, scratch);
+    else if (L == 16) jacobi_svd_t<1, 16, 2>(A, V, n, ld, lane, n_sweeps, scratch);
+    else if (rpl <= 2) jacobi_svd_t<2, 8, 2>(A, V, n, ld, lane, n_sweeps, scratch);
+    else jacobi_svd_t<4, 8, 2>(A, V, n, ld, lane, n_sweeps, scratch);
+}
+
 }  // namespace
 
 // LDS (doubles): A, V, Y, X of n x (n+1) each, wts[n] ; ints: view[n].  The constant matrix W of matchSVT
@@ -460,6 +473,250 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Register-state form for up to 32 detections (two waves per frame).  X, Y and W of matchSVT are element-wise state:
+// thread t owns the pairs (i <= l) number t, t + 128, ... (at most 5 of the 528) and keeps x = X[i][l] = X[l][i],
+// y_il, y_li and w for them in registers.  LDS then holds only A, V and B = X + Y/mu (the SVT input, rebuilt by the
+// owners after every update): 3 matrices instead of 4 leave room for 6 frames per CU instead of 4, i.e. 3 waves per
+// SIMD for the latency-bound Jacobi chain.  Arithmetic, order of operations and results are those of
+// p2s_assoc_kernel.
+template <typename T>
+__global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs a) {
+    constexpr int NW = 2, NT = 128, KP = 5;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_max = a.Nmax;                       // even, <= 32
+    const int mat = n_max * (n_max + 1);
+    double *A = reinterpret_cast<double *>(smem);
+    double *V = A + mat;
+    double *B = V + mat;
+    double *wts = B + mat;
+    double *scratch = wts + n_max;
+    int *view = reinterpret_cast<int *>(scratch + 4);
+    double *rays = A;                               // [person][joint in chunk][7], aliases A, V, B
+    const int lane = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int C = a.C, Kj = a.Kj;
+    double *out = a.affinity + f * (int64_t)n_max * n_max;
+
+    int N = 0;
+    for (int c = 0; c < C; ++c) {
+        const int pc = a.n_persons[f * C + c];
+        for (int i = lane; i < pc; i += NT)
+            if (N + i < n_max) view[N + i] = c;
+        N += pc;
+    }
+    N = min(N, n_max);
+    const int n = max(2, (N + 1) & ~1);
+    const int ld = n + 1;
+    for (int i = N + lane; i < n; i += NT) view[i] = -1 - i;
+    for (int i = lane; i < n_max * n_max; i += NT) out[i] = 0.0;
+    lds_fence<NW>();
+    if (N == 0) return;
+
+    // the pairs this thread owns
+    int pi[KP], pl[KP];
+    bool own[KP];                                   // a pair of real detections (not the zero padding)
+    double x[KP], yil[KP], yli[KP], w[KP], num[KP], den[KP];
+    const int n_all = n * (n + 1) / 2;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int pr = lane + k * NT;
+        int l = (int)((sqrt(1.0 + 8.0 * (double)pr) - 1.0) * 0.5);
+        while (l * (l + 1) / 2 > pr) --l;
+        while ((l + 1) * (l + 2) / 2 <= pr) ++l;
+        pl[k] = l;
+        pi[k] = pr - l * (l + 1) / 2;               // i <= l
+        own[k] = pr < n_all && l < N;
+        x[k] = 0.0; yil[k] = 0.0; yli[k] = 0.0; w[k] = 0.0; num[k] = 0.0; den[k] = 0.0;
+    }
+
+    const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
+    const bool trace = a.debug_mode == 7;
+    uint64_t t_start = 0, t_aff = 0, t_prod = 0, t_svd = 0, t_upd = 0;
+    int n_sweeps = 0, n_iter = 0;
+    if (trace) t_start = __builtin_amdgcn_s_memtime();
+
+    // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
+    int Kc = (3 * mat) / (7 * N);
+    Kc = max(1, min(Kc, Kj));
+    for (int j0 = 0; j0 < Kj; j0 += Kc) {
+        const int kc = min(Kc, Kj - j0);
+        for (int it = lane; it < N * kc; it += NT) {          // compute_rays (:293-314)
+            const int i = it / kc, j = it - i * kc;
+            const P2sCam &cam = a.cams[view[i]];
+            const T *o = kp + ((int64_t)i * Kj + j0 + j) * 3;
+            const double ox = (double)o[0], oy = (double)o[1], lik = (double)o[2];
+            const double v0 = cam.iK[0] * ox + cam.iK[1] * oy + cam.iK[2] - cam.T[0];
+            const double v1 = cam.iK[3] * ox + cam.iK[4] * oy + cam.iK[5] - cam.T[1];
+            const double v2 = cam.iK[6] * ox + cam.iK[7] * oy + cam.iK[8] - cam.T[2];
+            const double l0 = cam.R[0] * v0 + cam.R[3] * v1 + cam.R[6] * v2 - cam.center[0];
+            const double l1 = cam.R[1] * v0 + cam.R[4] * v1 + cam.R[7] * v2 - cam.center[1];
+            const double l2 = cam.R[2] * v0 + cam.R[5] * v1 + cam.R[8] * v2 - cam.center[2];
+            const double nrm = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+            double d0 = l0 / nrm, d1 = l1 / nrm, d2 = l2 / nrm;
+            double m0 = cam.center[1] * d2 - cam.center[2] * d1;
+            double m1 = cam.center[2] * d0 - cam.center[0] * d2;
+            double m2 = cam.center[0] * d1 - cam.center[1] * d0;
+            double lk = lik;
+            const bool anynan = !(d0 == d0) || !(d1 == d1) || !(d2 == d2) || !(m0 == m0) || !(m1 == m1) ||
+                                !(m2 == m2) || !(lk == lk);
+            if (anynan) { d0 = d1 = d2 = m0 = m1 = m2 = lk = 0.0; }
+            double *r = rays + ((size_t)i * kc + j) * 7;
+            r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1; r[5] = m2; r[6] = lk;
+        }
+        lds_fence<NW>();
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {                        // compute_affinity (:383-394) for the owned pairs
+            if (!own[k] || pi[k] == pl[k] || view[pi[k]] == view[pl[k]]) continue;
+            const double *r0 = rays + (size_t)pi[k] * kc * 7, *r1 = rays + (size_t)pl[k] * kc * 7;
+            double nm = 0.0, dn = 0.0;
+            for (int j = 0; j < kc; ++j) {
+                const double *p0 = r0 + j * 7, *p1 = r1 + j * 7;
+                const double prod = (p0[0] * p1[3] + p0[1] * p1[4] + p0[2] * p1[5]) +
+                                    (p1[0] * p0[3] + p1[1] * p0[4] + p1[2] * p0[5]);
+                const double lk = sqrt(p0[6] * p1[6]);
+                nm = fma(fabs(prod), lk, nm);
+                dn += lk;
+            }
+            num[k] += nm;
+            den[k] += dn;
+        }
+        lds_fence<NW>();
+    }
+    // distance -> affinity (:397-406), circular constraint (:794-795), matchSVT initialisation (:467-475)
+    const double thr = a.recon_thr;
+    for (int i = lane; i < n * ld; i += NT) B[i] = 0.0;
+    lds_fence<NW>();
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (lane + k * NT >= n_all) continue;
+        const int i = pi[k], l = pl[k];
+        if (i == l) { x[k] = 0.0; w[k] = a.w_sparse; continue; }
+        double aff = 0.0;
+        if (i < N && l < N && view[i] != view[l]) {
+            double d = num[k] / (1e-5 + den[k]);
+            d = d > thr ? thr : d;
+            aff = 1.0 - d / thr;
+        }
+        x[k] = aff;
+        w[k] = a.w_sparse - aff;
+        B[i * ld + l] = aff; B[l * ld + i] = aff;             // B = X + Y/mu with Y = 0
+    }
+    lds_fence<NW>();
+    if (trace) t_aff = __builtin_amdgcn_s_memtime() - t_start;
+
+    // ---- matchSVT (:477-505) --------------------------------------------------------------
+    double mu = 64.0;
+    for (int iter = 0; iter < a.max_iter; ++iter) {
+        uint64_t tt0 = 0;
+        if (trace) { tt0 = __builtin_amdgcn_s_memtime(); ++n_iter; }
+        if (iter == 0) {
+            for (int i = lane; i < n * n; i += NT) {
+                const int r = i / n, c = i - r * n;
+                A[c * ld + r] = B[r * ld + c];
+                V[c * ld + r] = (r == c) ? 1.0 : 0.0;
+            }
+        } else {                                              // warm start: A = B . V_prev
+            const int lpr = max(1, NT / n);
+            const int row = lane % n, part = lane / n;
+            const int cpl = (n + lpr - 1) / lpr;
+            const bool on = part < lpr;
+            {                                                 // n <= 32 and 128 threads: at most 8 columns per thread
+                double acc[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) acc[jj] = 0.0;
+                const int j0 = part * cpl;
+                const int nj = on ? max(0, min(min(8, cpl), n - j0)) : 0;
+                for (int kk = 0; kk < n; ++kk) {
+                    const double bk = B[row * ld + kk];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        if (jj < nj) acc[jj] = fma(bk, V[(j0 + jj) * ld + kk], acc[jj]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    if (jj < nj) A[(j0 + jj) * ld + row] = acc[jj];
+            }
+        }
+        lds_fence<NW>();
+        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_prod += t - tt0; tt0 = t; }
+        jacobi_svd_small2(A, V, n, ld, lane, n_sweeps, scratch);
+        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_svd += t - tt0; tt0 = t; }
+        const double tsv = a.w_rank / mu;
+        for (int j = lane; j < n; j += NT) {
+            double s2 = 0.0;
+            for (int r = 0; r < n; ++r) s2 = fma(A[j * ld + r], A[j * ld + r], s2);
+            const double sg = sqrt(s2);
+            wts[j] = (sg > tsv) ? (sg - tsv) / sg : 0.0;
+        }
+        lds_fence<NW>();
+        double pres2 = 0.0, dres2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            if (!own[k]) continue;
+            const int i = pi[k], l = pl[k];
+            double q_il = 0.0, q_li = 0.0;                    // SVT (:443-445): U diag(max(s-t,0)) Vt
+            for (int j = 0; j < n; ++j) {
+                const double wj = wts[j];
+                q_il = fma(wj * A[j * ld + i], V[j * ld + l], q_il);
+                q_li = fma(wj * A[j * ld + l], V[j * ld + i], q_li);
+            }
+            const bool same_view = view[i] == view[l];
+            double x_il = q_il - (w[k] + yil[k]) / mu;        // :482
+            double x_li = q_li - (w[k] + yli[k]) / mu;
+            if (same_view) { x_il = 0.0; x_li = 0.0; }        // :485-487
+            if (i == l) { x_il = 1.0; x_li = 1.0; }           // :490
+            x_il = x_il < 0.0 ? 0.0 : x_il; x_il = x_il > 1.0 ? 1.0 : x_il;   // :491-492
+            x_li = x_li < 0.0 ? 0.0 : x_li; x_li = x_li > 1.0 ? 1.0 : x_li;
+            const double cc = (same_view && i != l) ? 0.0 : 1.0;              // :495
+            x_il *= cc; x_li *= cc;
+            const double sym = (x_il + x_li) / 2;             // :496
+            const double old = x[k];
+            yil[k] = yil[k] + mu * (sym - q_il);              // :497
+            pres2 += (sym - q_il) * (sym - q_il);
+            dres2 += (sym - old) * (sym - old);
+            if (i != l) {
+                yli[k] = yli[k] + mu * (sym - q_li);
+                pres2 += (sym - q_li) * (sym - q_li);
+                dres2 += (sym - old) * (sym - old);
+            }
+            x[k] = sym;
+        }
+        if (trace) t_upd += __builtin_amdgcn_s_memtime() - tt0;
+        const double pRes = sqrt(block_sum<NW>(pres2, scratch, lane)) / (double)N;          // :500
+        const double dRes = mu * sqrt(block_sum<NW>(dres2, scratch, lane)) / (double)N;     // :501
+        if (pRes < a.tol && dRes < a.tol) break;                        // :502
+        if (pRes > 10 * dRes) mu = 2 * mu;                              // :504
+        else if (dRes > 10 * pRes) mu = mu / 2;                         // :505
+        // the next pass's SVT input, B = X + Y/mu (:480), from the owners
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            if (!own[k]) continue;
+            const int i = pi[k], l = pl[k];
+            B[i * ld + l] = x[k] + yil[k] * 1.0 / mu;
+            if (i != l) B[l * ld + i] = x[k] + yli[k] * 1.0 / mu;
+        }
+        lds_fence<NW>();
+    }
+    // ---- min_affinity cut (:800) and store --------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (!own[k]) continue;
+        const int i = pi[k], l = pl[k];
+        const double v = (x[k] < a.min_affinity) ? 0.0 : x[k];
+        out[i * n_max + l] = v;
+        out[l * n_max + i] = v;
+    }
+    if (trace) {
+        lds_fence<NW>();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (lane == 0) {
+            out[0] = (double)(__builtin_amdgcn_s_memtime() - t_start); out[1] = (double)t_aff; out[2] = (double)t_prod;
+            out[3] = (double)t_svd; out[4] = (double)t_upd; out[5] = (double)n_sweeps; out[6] = (double)n_iter; out[7] = (double)N;
+        }
+    }
+}
+
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
     const size_t lds = (size_t)(4 * a.Nmax * (a.Nmax + 1) + a.Nmax + 4) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
     // two waves per frame from 18 detections up: the Jacobi step is a chain of dependent operations, and with
@@ -473,6 +730,16 @@ hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(threads), lds, s, a);
         return hipGetLastError();
     };
+    if (two && a.Nmax <= 32 && !getenv("P2S_ASSOC_LDS_STATE")) {      // element-wise state in registers: 3 matrices in LDS
+        const size_t lds3 = (size_t)(3 * a.Nmax * (a.Nmax + 1) + a.Nmax + 4) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
+        auto go3 = [&](auto kern) -> hipError_t {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (err != hipSuccess) return err;
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(128), lds3, s, a);
+            return hipGetLastError();
+        };
+        return dtype == P2S_F32 ? go3(&p2s_assoc_kernel_r<float>) : go3(&p2s_assoc_kernel_r<double>);
+    }
     if (dtype == P2S_F32) e = two ? go(&p2s_assoc_kernel<float, 2>, 128) : go(&p2s_assoc_kernel<float, 1>, 64);
     else e = two ? go(&p2s_assoc_kernel<double, 2>, 128) : go(&p2s_assoc_kernel<double, 1>, 64);
     return e;
