@@ -1182,11 +1182,26 @@ __global__ void __launch_bounds__(64) p2s_single_kernel(const P2sSingleArgs a) {
                 double q[3];
                 smallest_eigvec(N, q);
                 if (__popc(kept) < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
+                // reprojection error as in kernel 1: one reciprocal square root per camera, the literal formula with
+                // the reference's NaN rules only when some wanted camera is degenerate
                 double sum = 0.0;
+                bool irregular = false;
                 for (int c = 0; c < C; ++c) {
                     const double *o = tk + ((size_t)c * PMAX + my_ids[c]) * 3;
-                    const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], o[0], o[1]);
-                    sum += (go && ((kept >> c) & 1u)) ? d : 0.0;
+                    const bool k = go && ((kept >> c) & 1u);
+                    bool reg;
+                    const double d = camera_distance<false>(cams + c, q, o[0], o[1], reg);
+                    irregular = irregular || (k && !reg);
+                    sum += k ? d : 0.0;
+                }
+                if (__any(irregular)) {
+                    double sum2 = 0.0;
+                    for (int c = 0; c < C; ++c) {
+                        const double *o = tk + ((size_t)c * PMAX + my_ids[c]) * 3;
+                        const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], o[0], o[1]);
+                        sum2 += (go && ((kept >> c) & 1u)) ? d : 0.0;
+                    }
+                    sum = irregular ? sum2 : sum;
                 }
                 // One camera left: weighted_triangulation (common.py:327-356) returns NaN for fewer than 4 rows
                 // and euclidean_distance turns the all-NaN difference into inf.
