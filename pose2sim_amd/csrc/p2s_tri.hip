@@ -656,8 +656,9 @@ __global__ void __launch_bounds__(256, (CT <= 8 ? 4 : 3)) p2s_tri_level0_direct_
     if (lu - lane >= n_units) return;                                      // whole wave past the chunk
     const bool active = lu < n_units;
     const int64_t u = active ? lu : 0;
-    const int64_t b = u / K;
-    const int k = (int)(u - b * K);
+    const uint32_t b32 = (uint32_t)u / (uint32_t)K;            // a chunk holds < 2^31 units: 32-bit division
+    const int64_t b = (int64_t)b32;
+    const int k = (int)((uint32_t)u - b32 * (uint32_t)K);
     const int64_t gb = a.block0 + b;
     const T *base = reinterpret_cast<const T *>(a.xyl) + (a.debug_mode == 2 ? 0 : gb * (int64_t)C * K * 3);
 

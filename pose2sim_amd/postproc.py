@@ -25,12 +25,8 @@ def sort_people_sports2d(keyptpre, keypt, max_dist=None):
     if n_prev == 0:
         return np.array([]), keypt
     diff = keypt[np.newaxis, :, :, :] - keyptpre[:, np.newaxis, :, :]
-    with np.errstate(invalid='ignore'):
-        per_kpt = np.sqrt(np.nansum(diff ** 2, axis=3))
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore', category=RuntimeWarning)
-        dist_matrix = np.nanmean(per_kpt, axis=2)
+    per_kpt = np.sqrt(np.nansum(diff ** 2, axis=3))        # an all-NaN keypoint sums to 0, so nothing here is NaN
+    dist_matrix = np.nanmean(per_kpt, axis=2)
     dist_matrix = np.nan_to_num(dist_matrix, nan=1e10, posinf=1e10)
     pre_ids, curr_ids = linear_sum_assignment(dist_matrix)
     if max_dist is not None:
