@@ -1015,11 +1015,6 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                     if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
                     const double e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
                     if (go && (e < be || brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
-                    if (LRSWAP && M > 2) {
-                        double qs[3];
-                        const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
-                        if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
-                    }
                 }
 
                 // group argmin, first (lowest-rank) index on ties (np.nanargmin, :502; np.argmin, :568)
@@ -1030,13 +1025,39 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                     const double t0 = shfl_d(bq0, lane ^ off), t1 = shfl_d(bq1, lane ^ off), t2 = shfl_d(bq2, lane ^ off);
                     const uint32_t tS = __shfl(bS, lane ^ off, 64);
                     if (take) { be = oe; brank = orank; bq0 = t0; bq1 = t1; bq2 = t2; bS = tS; }
-                    if (LRSWAP) {
-                        const double xe = shfl_d(se, lane ^ off);
-                        const uint32_t xrank = __shfl(srank, lane ^ off, 64);
-                        const bool tk = (xrank != 0xffffffffu) && (srank == 0xffffffffu || xe < se || (xe == se && xrank < srank));
-                        const double s0 = shfl_d(sq0, lane ^ off), s1 = shfl_d(sq1, lane ^ off), s2 = shfl_d(sq2, lane ^ off);
-                        const uint32_t xS = __shfl(sS, lane ^ off, 64);
-                        if (tk) { se = xe; srank = xrank; sq0 = s0; sq1 = s1; sq2 = s2; sS = xS; }
+                }
+                // L/R-swap candidates (:509-579) only where the reference evaluates them: when the level's plain
+                // minimum is still above the threshold.  The last level of a unit -- the largest one -- usually
+                // succeeds without them, so this second pass over the subsets is mostly skipped.
+                if (LRSWAP) {
+                    const bool need_sw = (owner >= 0) && (M > 2) && (be > thr);
+                    if (__any(need_sw)) {
+                        for (uint32_t r0 = 0; r0 < nsub; r0 += G) {
+                            const uint32_t r = r0 + lig;
+                            bool go = need_sw && (r < nsub);
+                            uint32_t S = 0;
+                            if (go) {
+                                S = unrank_subset(r, C, level, sBinom);
+                                const uint32_t pad = S & o_d;
+                                const int np = __popc(pad);
+                                uint32_t low = 0, dd = o_d;
+                                for (int i = 0; i < np; ++i) { low |= dd & (0u - dd); dd &= dd - 1; }
+                                go = (pad == low);
+                            }
+                            if (!__any(go)) continue;
+                            const uint32_t kept = o_valid & ~(S & o_valid);
+                            double qs[3];
+                            const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                            if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
+                        }
+                        for (int off = G >> 1; off > 0; off >>= 1) {
+                            const double xe = shfl_d(se, lane ^ off);
+                            const uint32_t xrank = __shfl(srank, lane ^ off, 64);
+                            const bool tk = (xrank != 0xffffffffu) && (srank == 0xffffffffu || xe < se || (xe == se && xrank < srank));
+                            const double s0 = shfl_d(sq0, lane ^ off), s1 = shfl_d(sq1, lane ^ off), s2 = shfl_d(sq2, lane ^ off);
+                            const uint32_t xS = __shfl(sS, lane ^ off, 64);
+                            if (tk) { se = xe; srank = xrank; sq0 = s0; sq1 = s1; sq2 = s2; sS = xS; }
+                        }
                     }
                 }
                 // level result, identical in every lane of the group
