@@ -329,7 +329,11 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     // search kernel geometry: LDS = [P][binom][waves x 64 records]
     const int lds_binom_off = (C * 12 * 8 + 15) / 16 * 16;
     const int lds_rec_off = (lds_binom_off + 33 * 33 * 4 + 15) / 16 * 16;
-    int job = 40;                                      // records per search job (32..48 measure alike on cfg2)
+    // records per search job: 40 (32..48 measure alike on cfg2) unless the records are large -- a wave's LDS region
+    // (job x (record + state)) is kept near 9 KB so that 3 waves per SIMD stay resident; with 32 cameras and the
+    // swapped copy a 40-record job took 35 KB and left less than one wave per SIMD (10 records there: 4.6 -> 2.0 s
+    // together with the two-pass swap evaluation; deep searches also balance better with small jobs)
+    int job = (int)std::max<int64_t>(8, std::min<int64_t>(40, (9 * 1024) / (int64_t)(rec_bytes + 96)));
     if (const char *j = getenv("P2S_JOB")) job = std::max(8, std::min(64, atoi(j)));   // kernel experiments only
     const int64_t fit = (40 * 1024) / (job * (int64_t)(rec_bytes + 96));
     const int wpb = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;   // waves per search workgroup
