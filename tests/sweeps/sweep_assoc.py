@@ -1,6 +1,6 @@
 """Association parity sweep: GPU kernel against the NumPy oracle on many random frames (cfg3-like and harder)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench
 from oracle import association_ref as ar

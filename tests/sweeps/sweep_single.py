@@ -1,7 +1,7 @@
 """Single-person association parity sweep: GPU kernel against the NumPy oracle on many random frames."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'golden'))
 import numpy as np
 from multiprocessing import Pool
 from e2e_common import make_single_scene

@@ -1,6 +1,6 @@
 """Exhaustive parity sweep: every unit of several multi-million-unit workloads against the C oracle."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import tri_oracle
 from pose2sim_amd import skeletons, synth
