@@ -7,7 +7,7 @@ pins any of their outputs, so these are restatements of OpenCV's published algor
 (calib3d: Brown-Conrady model k1,k2,p1,p2[,k3[,k4,k5,k6]], 5 fixed-point iterations for the
 inverse).  PARITY UNPINNED against OpenCV itself; they are self-checked by round trip in
 tests/test_cvmath.py.  These run once per calibration (host side, C cameras), never per unit;
-the per-unit versions of undistort / project live in csrc/p2s_kernels.hip and oracle/.
+the per-unit versions of undistort / project live in csrc/p2s_tri.hip (and, for the tests, in oracle/).
 """
 import numpy as np
 
