@@ -2,7 +2,6 @@
 import os, sys
 os.environ['P2S_DEBUG_MODE'] = '7'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import bench
 from pose2sim_amd.engine import Engine
 cfg = dict(bench.CONFIGS['cfg3']); cfg['F'] = 4000

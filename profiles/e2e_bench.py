@@ -8,7 +8,7 @@ import sys
 import tempfile
 import time
 
-import numpy as np
+import numpy as np  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
