@@ -158,6 +158,23 @@ int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, con
                               const int64_t *offsets, const void *tracked, const p2s_single_params *params,
                               int32_t *comb, double *err, double *Q);
 
+/* Experiments and tests only -- nothing here changes a result, and the library never reads the environment.
+ *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernel with the in-wave subset search where it
+ *                         applies (pinhole, no L/R swap, <= 16 cameras), else the streaming + work-list search pair;
+ *                         P2S_TRI_PATH_WORKLIST: always the pair
+ *   P2S_TUNE_FORCE_TILED  1: the LDS-tiled streaming kernel even where observations fit in registers
+ *   P2S_TUNE_NO_OVERLAP   1: search kernels on the main stream instead of beside the next chunk's streaming pass
+ *   P2S_TUNE_SEARCH_JOB   work-list records a search wave takes at a time (8..64; 0 = automatic)
+ *   P2S_TUNE_DIAG_MODE    kernel diagnostics of a -DP2S_DIAG build (exp/README.md); refused by the shipped library */
+#define P2S_TUNE_TRI_PATH 1
+#define P2S_TUNE_FORCE_TILED 2
+#define P2S_TUNE_NO_OVERLAP 3
+#define P2S_TUNE_SEARCH_JOB 4
+#define P2S_TUNE_DIAG_MODE 5
+#define P2S_TRI_PATH_AUTO 0
+#define P2S_TRI_PATH_WORKLIST 1
+int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value);
+
 /* Kernel timing on the context's stream with HIP events: begin, enqueue work, end (blocks). */
 int p2s_timing_begin(p2s_ctx *ctx);
 int p2s_timing_end(p2s_ctx *ctx, float *elapsed_ms);

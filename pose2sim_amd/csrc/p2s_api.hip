@@ -73,6 +73,12 @@ struct p2s_ctx {
     hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
     Scratch in, swap, q, err, nexcl, mask, aux0, aux1;
     Scratch wl_rec, wl_count;
+    uint16_t *d_sub_tab = nullptr;                   // camera subsets by level (fused kernel), built with the calibration
+    uint32_t *d_sub_off = nullptr;
+    // p2s_set_tuning: experiments and tests only, never read from the environment
+    int tri_path = P2S_TRI_PATH_AUTO;
+    int force_tiled = 0, no_overlap = 0, job = 0;
+    int debug_mode = 0;                              // honoured by a -DP2S_DIAG build only
 };
 
 namespace {
@@ -217,6 +223,8 @@ int p2s_destroy(p2s_ctx *ctx) {
     ctx->wl_rec.release(); ctx->wl_count.release();
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->d_binom) (void)hipFree(ctx->d_binom);
+    if (ctx->d_sub_tab) (void)hipFree(ctx->d_sub_tab);
+    if (ctx->d_sub_off) (void)hipFree(ctx->d_sub_off);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -275,9 +283,61 @@ int p2s_set_calibration(p2s_ctx *ctx, int32_t n_cams, const double *P, const dou
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpy(ctx->d_cams, cams.data(), sizeof(P2sCam) * P2S_MAX_CAMS, hipMemcpyHostToDevice));
+    // every subset of the n_cams cameras as a bit mask, level by level in itertools.combinations order
+    // (triangulation.py:411): what the fused kernel's lanes index by (level, rank); 2^C entries, C <= 16
+    if (n_cams <= 16) {
+        std::vector<uint16_t> tab;
+        std::vector<uint32_t> off(n_cams + 2, 0);
+        tab.reserve((size_t)1 << n_cams);
+        for (int k = 0; k <= n_cams; ++k) {
+            off[k] = (uint32_t)tab.size();
+            std::vector<int> idx(k);
+            for (int i = 0; i < k; ++i) idx[i] = i;
+            for (;;) {
+                uint32_t m = 0;
+                for (int i = 0; i < k; ++i) m |= 1u << idx[i];
+                tab.push_back((uint16_t)m);
+                int i = k - 1;
+                while (i >= 0 && idx[i] == n_cams - k + i) --i;
+                if (i < 0) break;
+                ++idx[i];
+                for (int j = i + 1; j < k; ++j) idx[j] = idx[j - 1] + 1;
+            }
+        }
+        off[n_cams + 1] = (uint32_t)tab.size();
+        if (!ctx->d_sub_tab) HIP_TRY(hipMalloc((void **)&ctx->d_sub_tab, sizeof(uint16_t) << 16));
+        if (!ctx->d_sub_off) HIP_TRY(hipMalloc((void **)&ctx->d_sub_off, sizeof(uint32_t) * 18));
+        HIP_TRY(hipMemcpy(ctx->d_sub_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->d_sub_off, off.data(), off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     ctx->n_cams = n_cams;
     ctx->full_calib = full;
     return P2S_OK;
+}
+
+int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    switch (key) {
+    case P2S_TUNE_TRI_PATH:
+        if (value != P2S_TRI_PATH_AUTO && value != P2S_TRI_PATH_WORKLIST)
+            return fail(P2S_ERR_INVALID_ARG, "unknown triangulation path %d", value);
+        ctx->tri_path = value;
+        return P2S_OK;
+    case P2S_TUNE_FORCE_TILED: ctx->force_tiled = value ? 1 : 0; return P2S_OK;
+    case P2S_TUNE_NO_OVERLAP: ctx->no_overlap = value ? 1 : 0; return P2S_OK;
+    case P2S_TUNE_SEARCH_JOB:
+        if (value != 0 && (value < 8 || value > 64)) return fail(P2S_ERR_INVALID_ARG, "search job size %d outside [8, 64]", value);
+        ctx->job = value;
+        return P2S_OK;
+    case P2S_TUNE_DIAG_MODE:
+#ifdef P2S_DIAG
+        ctx->debug_mode = value;
+        return P2S_OK;
+#else
+        return fail(P2S_ERR_INVALID_ARG, "kernel diagnostics need a -DP2S_DIAG build of the library");
+#endif
+    default: return fail(P2S_ERR_INVALID_ARG, "unknown tuning key %d", key);
+    }
 }
 
 int p2s_tri_geometry(int32_t n_cams, int32_t n_kpts, int32_t dtype, int32_t *blocks_per_tile, int32_t *threads,
@@ -301,9 +361,33 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     if (!d_xyl || !d_Q || !d_err || !d_n_excl || !d_excl_mask) return fail(P2S_ERR_INVALID_ARG, "null device pointer");
     if (((uintptr_t)d_xyl & 15) != 0) return fail(P2S_ERR_INVALID_ARG, "xyl must be 16-byte aligned");
     const int C = ctx->n_cams;
+    const int elem = dtype == P2S_F32 ? 4 : 8;
+    if (ctx->tri_path == P2S_TRI_PATH_AUTO && !ctx->force_tiled &&
+        p2s_tri_fused_supports(C, dtype, params->undistort_points, params->handle_lr_swap)) {
+        // one launch per chunk: streaming pass + in-wave subset search (p2s_tri_fused.hip).  A chunk keeps the
+        // kernel's 32-bit byte offsets below 2^31 and starts on a multiple of 16 blocks (16-byte result stores).
+        P2sTriArgs a{};
+        a.xyl = d_xyl;
+        a.Q = d_Q; a.err = d_err; a.n_excl = d_n_excl; a.mask = d_excl_mask;
+        a.cams = ctx->d_cams;
+        a.sub_tab = ctx->d_sub_tab; a.sub_off = ctx->d_sub_off;
+        a.K = n_kpts; a.C = C;
+        a.min_cams = params->min_cameras;
+        a.thr = params->reproj_error_threshold;
+        a.lik_thr = params->likelihood_threshold;
+        const int64_t blk_bytes = (int64_t)C * n_kpts * 3 * elem;
+        if (blk_bytes > ((int64_t)1 << 26)) return fail(P2S_ERR_INVALID_ARG, "K=%d too large", n_kpts);
+        const int64_t chunk_blocks = std::max<int64_t>(16, (((int64_t)1 << 31) / blk_bytes) / 16 * 16);
+        HIP_TRY(hipSetDevice(ctx->device));
+        for (int64_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks) {
+            a.block0 = b0;
+            a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - b0);
+            HIP_TRY(p2s_launch_tri_fused(a, dtype, ctx->stream));
+        }
+        return P2S_OK;
+    }
     Geometry g = choose_geometry(C, n_kpts, dtype);
     if (g.FB == 0) return fail(P2S_ERR_INVALID_ARG, "one block of C=%d x K=%d does not fit in LDS", C, n_kpts);
-    const int elem = dtype == P2S_F32 ? 4 : 8;
     const int rec_bytes = P2S_REC_HDR + (3 * C * elem * (params->handle_lr_swap ? 2 : 1) + 15) / 16 * 16;
 
     // chunks of whole tiles, at most kChunkUnits units each
@@ -334,7 +418,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     // swapped copy a 40-record job took 35 KB and left less than one wave per SIMD (10 records there: 4.6 -> 2.0 s
     // together with the two-pass swap evaluation; deep searches also balance better with small jobs)
     int job = (int)std::max<int64_t>(8, std::min<int64_t>(40, (9 * 1024) / (int64_t)(rec_bytes + 96)));
-    if (const char *j = getenv("P2S_JOB")) job = std::max(8, std::min(64, atoi(j)));   // kernel experiments only
+    if (ctx->job) job = ctx->job;                                                        // p2s_set_tuning: kernel experiments only
     const int64_t fit = (40 * 1024) / (job * (int64_t)(rec_bytes + 96));
     const int wpb = fit >= 4 ? 4 : fit >= 2 ? 2 : 1;   // waves per search workgroup
     const int lds1 = lds_rec_off + wpb * job * (rec_bytes + 96);  // per wave: `job` records + `job` owner states
@@ -356,7 +440,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     a.lr_swap = params->handle_lr_swap ? 1 : 0;
     a.thr = params->reproj_error_threshold;
     a.lik_thr = params->likelihood_threshold;
-    if (const char *dbg = getenv("P2S_DEBUG_MODE")) a.debug_mode = atoi(dbg);   // diagnostics only
+    a.debug_mode = ctx->debug_mode;                                   // 0 unless a -DP2S_DIAG build was told otherwise
 
     for (int64_t ch = 0; ch < n_chunks; ++ch) {
         a.block0 = ch * chunk_blocks;
@@ -374,15 +458,15 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         L.grid1 = (int)((waves + wpb - 1) / wpb);
         L.threads1 = 64 * wpb;
         L.lds1 = lds1;
-        L.force_tiled = getenv("P2S_FORCE_TILED") ? 1 : 0;   // diagnostics / tests of the tiled kernel
+        L.force_tiled = ctx->force_tiled;                    // p2s_set_tuning: tests of the tiled kernel
         const int slot = (int)(ch & 1);
-        const bool overlap = n_chunks > 1 && !getenv("P2S_NO_OVERLAP");
+        const bool overlap = n_chunks > 1 && !ctx->no_overlap;
         hipStream_t side = overlap ? ctx->side_stream : ctx->stream;
         if (overlap && ch >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[slot], 0));   // list `slot` is free again
         HIP_TRY(p2s_launch_tri(a, dtype, L, ctx->stream, side, ctx->ev_k1[slot]));
         if (overlap) HIP_TRY(hipEventRecord(ctx->ev_k2[slot], side));
     }
-    if (n_chunks > 1 && !getenv("P2S_NO_OVERLAP")) {   // join: the caller's stream sees every search finished
+    if (n_chunks > 1 && !ctx->no_overlap) {   // join: the caller's stream sees every search finished
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[(n_chunks - 1) & 1], 0));
         if (n_chunks > 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[(n_chunks - 2) & 1], 0));
     }
@@ -452,7 +536,7 @@ int p2s_associate_device(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, in
     a.cams = ctx->d_cams;
     a.n_frames = n_frames; a.C = ctx->n_cams; a.Kj = n_kpts_json; a.Nmax = n_max;
     a.max_iter = params->max_iter;
-    if (const char *dbg = getenv("P2S_DEBUG_MODE")) a.debug_mode = atoi(dbg);   // diagnostics only
+    a.debug_mode = ctx->debug_mode;
     a.recon_thr = params->reconstruction_error_threshold; a.min_affinity = params->min_affinity;
     a.w_rank = params->w_rank; a.tol = params->tol; a.w_sparse = params->w_sparse;
     HIP_TRY(hipSetDevice(ctx->device));

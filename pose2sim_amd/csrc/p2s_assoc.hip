@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
 
     const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
     const int n_pairs = N * (N - 1) / 2;
-    const bool trace = a.debug_mode == 7;
+    const bool trace = P2S_DEBUG_MODE(a) == 7;
     uint64_t t_start = 0, t_aff = 0, t_prod = 0, t_svd = 0, t_upd = 0;
     int n_sweeps = 0, n_iter = 0;
     if (trace) t_start = __builtin_amdgcn_s_memtime();
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs 
     }
 
     const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
-    const bool trace = a.debug_mode == 7;
+    const bool trace = P2S_DEBUG_MODE(a) == 7;
     uint64_t t_start = 0, t_aff = 0, t_prod = 0, t_svd = 0, t_upd = 0;
     int n_sweeps = 0, n_iter = 0;
     if (trace) t_start = __builtin_amdgcn_s_memtime();

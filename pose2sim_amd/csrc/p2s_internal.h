@@ -18,6 +18,14 @@ struct P2sCam {
     double center[3];      // -R^T T                            (association rays)
 };
 
+// Kernel diagnostics (phase stamps, memory-skeleton modes) exist only in a -DP2S_DIAG build (exp/README.md): in the
+// shipped library the mode is the constant 0 and every branch on it is compiled out.
+#ifdef P2S_DIAG
+#define P2S_DEBUG_MODE(a) ((a).debug_mode)
+#else
+#define P2S_DEBUG_MODE(a) 0
+#endif
+
 #define P2S_MAX_SUBSETS_PER_LEVEL (1u << 26)   // search kernel: deeper levels are not entered (see p2s_tri.hip)
 // The work list is cut into shards (workgroup b appends to shard b % P2S_WL_SHARDS) so that the
 // append counters do not serialise: one returning atomic per wave on ONE word caps near 90 per us.
@@ -33,6 +41,8 @@ struct P2sTriArgs {
     uint32_t *mask;
     const P2sCam *cams;
     const uint32_t *binom;       // [33][33] binomial coefficients
+    const uint16_t *sub_tab;     // fused kernel (C <= 16): every camera subset as a bit mask, by level, in itertools.combinations order
+    const uint32_t *sub_off;     // [C + 2] start of level k in sub_tab
     uint32_t *wl_count;          // work list of this chunk: P2S_WL_SHARDS record counts, then P2S_WL_SHARDS job tickets (zeroed before kernel 1)
     unsigned char *wl_rec;       // records: {u32 unit id in chunk, pad to 16 B, T obs[C][3] (, T obs_swapped[C][3]), pad to 16 B}
     int64_t block0;              // first (frame, person) block of this chunk
@@ -67,6 +77,9 @@ struct P2sAssocArgs {
 
 hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
                           hipEvent_t k1_done);
+// p2s_tri_fused.hip: streaming pass + in-wave subset search in one launch (pinhole, no L/R swap, C <= 16)
+bool p2s_tri_fused_supports(int C, int dtype, int undistort, int lr_swap);
+hipError_t p2s_launch_tri_fused(const P2sTriArgs &a, int dtype, hipStream_t s);
 struct P2sSingleArgs {
     const int32_t *n_persons;   // [F][C]
     const int64_t *offsets;     // [F+1]

@@ -87,6 +87,13 @@ class Engine:
     def synchronize(self):
         _lib.check(self._lib.p2s_synchronize(self._h))
 
+    # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
+    TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE = 1, 2, 3, 4, 5
+    TRI_PATH_AUTO, TRI_PATH_WORKLIST = 0, 1
+
+    def set_tuning(self, key, value):
+        _lib.check(self._lib.p2s_set_tuning(self._h, int(key), int(value)))
+
     # -- triangulation ---------------------------------------------------------------------
     @staticmethod
     def tri_params(thr, lik_thr, min_cams, undistort=False, lr_swap=False):
@@ -114,6 +121,37 @@ class Engine:
                                                   _ptr(Q), _ptr(err), _ptr(nex), _ptr(mask)))
         return (Q.reshape(lead + (K, 3)), err.reshape(lead + (K,)), nex.reshape(lead + (K,)),
                 mask.reshape(lead + (K,)))
+
+    def triangulate_packed(self, xyl, params, swap_idx=None, pad_blocks=None):
+        """Multi-GPU form of triangulate(): the observations go up, the kernels run, and the results STAY on this GPU
+        in one packed uint8 torch tensor (parallel.section_offsets layout, sections sized for pad_blocks >= n_blocks
+        blocks, zero beyond this call's blocks) -- the operand of the path's single all-gather.  Returns a
+        parallel.PackedDeviceResults."""
+        import torch
+        from . import parallel
+        xyl, dtype = as_packed(xyl)
+        Cn, K = xyl.shape[-3], xyl.shape[-2]
+        if Cn != self.n_cams or xyl.shape[-1] != 3:
+            raise P2sError(f'xyl has shape {xyl.shape}; expected [..., {self.n_cams}, K, 3]')
+        nb = int(np.prod(xyl.shape[:-3])) if xyl.ndim > 3 else 1
+        pad = nb if pad_blocks is None else int(pad_blocks)
+        if pad < nb:
+            raise P2sError(f'pad_blocks={pad} < {nb} blocks')
+        dev = torch.device('cuda', self.device)
+        off_e, off_m, off_n, total = parallel.section_offsets(pad * K)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev)
+            buf = torch.zeros(max(total, 16), dtype=torch.uint8, device=dev)
+            if nb:
+                d_x = torch.from_numpy(xyl.reshape(-1)).to(dev)
+                d_sw = None
+                if swap_idx is not None:
+                    d_sw = torch.from_numpy(np.ascontiguousarray(np.asarray(swap_idx, dtype=np.int32))).to(dev)
+                self.set_stream(stream.cuda_stream)
+                b = buf.data_ptr()
+                self.triangulate_device(nb, K, dtype, d_x, d_sw, params, b, b + off_e, b + off_n, b + off_m)
+                stream.synchronize()                   # d_x / d_sw may be freed when this returns
+        return parallel.PackedDeviceResults(buf, nb, pad, K)
 
     def triangulate_device(self, n_blocks, K, dtype, d_xyl, d_swap, params, d_Q, d_err, d_nexcl, d_mask):
         """Device-resident operands (tensors or raw pointers); enqueues on the engine's stream."""

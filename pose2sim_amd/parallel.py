@@ -12,7 +12,9 @@ import numpy as np
 
 
 def dist_info():
-    """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use."""
+    """(rank, world) of the default process group, (0, 1) when torch.distributed is not in use.
+    A process launched as one of several ranks (WORLD_SIZE > 1) that has not initialised the process group would
+    take every frame and write the same files as its siblings: that is refused."""
     import sys
     if 'torch' not in sys.modules and 'WORLD_SIZE' not in os.environ:
         return 0, 1                  # single process that never touched torch: do not pay its import (~2-5 s)
@@ -22,7 +24,22 @@ def dist_info():
             return dist.get_rank(), dist.get_world_size()
     except ImportError:
         pass
+    if int(os.environ.get('WORLD_SIZE', '1') or 1) > 1:
+        raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call "
+                           "torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', LOCAL_RANK)) "
+                           "before the Pose2Sim stage, or unset WORLD_SIZE for a single-process run")
     return 0, 1
+
+
+def collective_device():
+    """Where this rank's collective operands live: its own GPU for RCCL (backend 'nccl') -- cuda:LOCAL_RANK, the same
+    source the HIP engine takes its device from (triangulation._make_engine), NOT torch's current device, which is
+    cuda:0 in every rank unless somebody called set_device -- and the host for gloo."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == 'nccl':
+        return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    return torch.device('cpu')
 
 
 def shard_bounds(n_frames, rank, world):
@@ -33,23 +50,50 @@ def shard_bounds(n_frames, rank, world):
     return lo, hi
 
 
+def section_offsets(n_units):
+    """Byte offsets of the four sections of a packed result buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8] for
+    n_units units, each section starting on 16 bytes (the kernels store 16 bytes per lane), and the total size."""
+    a16 = lambda v: (v + 15) // 16 * 16                                # noqa: E731
+    off_e = a16(n_units * 24)
+    off_m = a16(off_e + n_units * 4)
+    off_n = a16(off_m + n_units * 4)
+    return off_e, off_m, off_n, a16(off_n + n_units)
+
+
 def pack_results(Q, err, nex, mask):
-    """[n][K] results -> one contiguous uint8 buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8]."""
-    parts = [np.ascontiguousarray(Q, dtype=np.float64).view(np.uint8).ravel(),
-             np.ascontiguousarray(err, dtype=np.float32).view(np.uint8).ravel(),
-             np.ascontiguousarray(mask, dtype=np.uint32).view(np.uint8).ravel(),
-             np.ascontiguousarray(nex, dtype=np.uint8).ravel()]
-    return np.concatenate(parts)
+    """[n][K] results -> one contiguous uint8 buffer (layout: section_offsets)."""
+    Q = np.ascontiguousarray(Q, dtype=np.float64)
+    n = Q.size // 3
+    off_e, off_m, off_n, total = section_offsets(n)
+    buf = np.zeros(total, dtype=np.uint8)
+    buf[:n * 24] = Q.view(np.uint8).ravel()
+    buf[off_e:off_e + n * 4] = np.ascontiguousarray(err, dtype=np.float32).view(np.uint8).ravel()
+    buf[off_m:off_m + n * 4] = np.ascontiguousarray(mask, dtype=np.uint32).view(np.uint8).ravel()
+    buf[off_n:off_n + n] = np.ascontiguousarray(nex, dtype=np.uint8).ravel()
+    return buf
 
 
 def unpack_results(buf, n_blocks, K):
     n = n_blocks * K
-    o = 0
-    Q = buf[o:o + n * 24].view(np.float64).reshape(n_blocks, K, 3); o += n * 24
-    err = buf[o:o + n * 4].view(np.float32).reshape(n_blocks, K); o += n * 4
-    mask = buf[o:o + n * 4].view(np.uint32).reshape(n_blocks, K); o += n * 4
-    nex = buf[o:o + n].reshape(n_blocks, K)
+    off_e, off_m, off_n, _ = section_offsets(n)
+    Q = buf[:n * 24].view(np.float64).reshape(n_blocks, K, 3)
+    err = buf[off_e:off_e + n * 4].view(np.float32).reshape(n_blocks, K)
+    mask = buf[off_m:off_m + n * 4].view(np.uint32).reshape(n_blocks, K)
+    nex = buf[off_n:off_n + n].reshape(n_blocks, K)
     return Q, err, nex, mask
+
+
+class PackedDeviceResults:
+    """Results of one rank's frame block left on its GPU: `buf` is a uint8 torch tensor in the packed layout
+    (section_offsets) for `n_blocks_padded` blocks of K units, of which the first `n_blocks` are this rank's."""
+
+    def __init__(self, buf, n_blocks, n_blocks_padded, K):
+        self.buf, self.n_blocks, self.n_blocks_padded, self.K = buf, n_blocks, n_blocks_padded, K
+
+
+def largest_shard(F, world):
+    lo, hi = shard_bounds(F, 0, world)
+    return hi - lo
 
 
 def sharded_triangulate(compute, xyl):
@@ -66,28 +110,40 @@ def sharded_triangulate(compute, xyl):
     return gather_results(compute(xyl[lo:hi]), F, xyl.shape[1], xyl.shape[3])
 
 
-def gather_results(local, F, Pn, K):
+def gather_results(local, F, Pn, K, host_copy_on=None):
     """The single collective of the path: every rank contributes the results of its contiguous frame block
-    (``shard_bounds``) and receives the whole trajectory.  local = (Q [n][Pn][K][3], err, n_excl, mask)."""
+    (``shard_bounds``) and receives the whole trajectory.
+
+    local: (Q [n][Pn][K][3], err, n_excl, mask) host arrays, or a PackedDeviceResults (Engine.triangulate_packed):
+    then the all-gather runs on the device buffers as they are -- no copy to the host, NumPy pack and copy back --
+    and the gathered buffer comes to the host once.  host_copy_on: None = every rank returns the trajectory; a rank
+    number = only that rank copies it to the host and the others return None (the sequential post-processing and
+    the file writes are that rank's alone)."""
     rank, world = dist_info()
-    Q, err, nex, mask = local
-    if world == 1 and not os.environ.get('P2S_FORCE_COLLECTIVE'):
-        return Q, err, nex, mask
+    device_form = isinstance(local, PackedDeviceResults)
+    if world == 1 and not os.environ.get('P2S_FORCE_COLLECTIVE') and not device_form:
+        return local
     import torch
     import torch.distributed as dist
-    lo, hi = shard_bounds(F, rank, world)
-    nb_max = (shard_bounds(F, 0, world)[1] - shard_bounds(F, 0, world)[0]) * Pn
-    per_unit = 24 + 4 + 4 + 1
-    local_buf = np.zeros(nb_max * K * per_unit, dtype=np.uint8)
-    nb = (hi - lo) * Pn
-    # sections are sized for the largest block: pad the local block to it
-    local_buf[:] = pack_results(_pad(np.asarray(Q).reshape(nb, K, 3), nb_max), _pad(np.asarray(err).reshape(nb, K), nb_max),
-                                _pad(np.asarray(nex).reshape(nb, K), nb_max), _pad(np.asarray(mask).reshape(nb, K), nb_max))
-    backend = dist.get_backend()
-    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-    t_local = torch.from_numpy(local_buf).to(dev)
-    t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(t_all, t_local)          # the single collective of the path
+    nb_max = largest_shard(F, world) * Pn
+    if device_form:
+        assert local.n_blocks_padded == nb_max and local.K == K
+        t_local = local.buf
+    else:
+        Q, err, nex, mask = local
+        lo, hi = shard_bounds(F, rank, world)
+        nb = (hi - lo) * Pn
+        # sections are sized for the largest block: pad the local block to it
+        local_buf = pack_results(_pad(np.asarray(Q).reshape(nb, K, 3), nb_max), _pad(np.asarray(err).reshape(nb, K), nb_max),
+                                 _pad(np.asarray(nex).reshape(nb, K), nb_max), _pad(np.asarray(mask).reshape(nb, K), nb_max))
+        t_local = torch.from_numpy(local_buf).to(collective_device())
+    if dist.is_available() and dist.is_initialized():
+        t_all = torch.empty(world * t_local.numel(), dtype=torch.uint8, device=t_local.device)
+        dist.all_gather_into_tensor(t_all, t_local)      # the single collective of the path
+    else:
+        t_all = t_local                                  # one process, device form: nothing to exchange
+    if host_copy_on is not None and rank != host_copy_on:
+        return None
     allbuf = t_all.cpu().numpy().reshape(world, -1)
     outs = []
     for r in range(world):
@@ -102,6 +158,13 @@ def gather_results(local, F, Pn, K):
     return Qf, ef, nf, mf
 
 
+def agree_ok(error=None):
+    """Every rank calls this before a collective with the exception its own stage raised (or None): if any rank
+    failed, all of them raise -- the failing one its own exception -- instead of one leaving and the others waiting
+    in the collective until the backend's timeout."""
+    agree_max(0, error)
+
+
 def agree_max(value, error=None):
     """max of an integer over the ranks, and every rank raises when any of them hit an error (so that a rank
     that cannot read its share of the files does not leave the others waiting in a collective)."""
@@ -112,14 +175,13 @@ def agree_max(value, error=None):
         return value
     import torch
     import torch.distributed as dist
-    backend = dist.get_backend()
-    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    dev = collective_device()
     t = torch.tensor([int(value), 1 if error is not None else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if int(t[1].item()):
         if error is not None:
             raise error
-        raise RuntimeError('another rank failed while reading its share of the pose files')
+        raise RuntimeError('another rank failed in its share of the stage (its own log has the exception)')
     return int(t[0].item())
 
 

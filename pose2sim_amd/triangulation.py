@@ -162,12 +162,30 @@ def triangulate_all(config_dict):
         nb_persons = 1
         if multi_person:                                   # the person count is a maximum over ALL files (:784)
             nb_persons = poseio.max_persons_sharded(pose_dir, json_dirs_names, json_files_names, rank, world)
-        xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, my_range, keypoints_ids, nb_persons)
-    engine = _make_engine()
-    engine.set_calibration(P, calib_params if undistort_points else None)
-    prm = engine.tri_params(error_threshold, likelihood_threshold, min_cameras, undistort_points, handle_LR_swap)
-    local = engine.triangulate(xyl, prm, keypoints_idx_swapped if handle_LR_swap else None)
-    Qk, ek, nk, mk = parallel.gather_results(local, n_frames, nb_persons, keypoints_nb)
+    # this rank's stage; whatever it raises is agreed with the other ranks BEFORE the collective, so that a rank that
+    # cannot read its files or has no memory left does not leave the others waiting in the all-gather
+    local, failure = None, None
+    try:
+        if not (multi_person and world == 1):
+            xyl = poseio.load_observations(pose_dir, json_dirs_names, maps, my_range, keypoints_ids, nb_persons)
+        engine = _make_engine()
+        engine.set_calibration(P, calib_params if undistort_points else None)
+        prm = engine.tri_params(error_threshold, likelihood_threshold, min_cameras, undistort_points, handle_LR_swap)
+        swap_arg = keypoints_idx_swapped if handle_LR_swap else None
+        if world > 1 and hasattr(engine, 'triangulate_packed') and parallel.collective_device().type == 'cuda':
+            # results stay on the GPU: the all-gather takes the packed device buffer as it is
+            local = engine.triangulate_packed(xyl, prm, swap_arg, pad_blocks=parallel.largest_shard(n_frames, world) * nb_persons)
+        else:
+            local = engine.triangulate(xyl, prm, swap_arg)
+    except Exception as exc:                               # noqa: BLE001 -- re-raised on every rank by agree_ok
+        if world == 1:
+            raise
+        failure = exc
+    parallel.agree_ok(failure)
+    gathered = parallel.gather_results(local, n_frames, nb_persons, keypoints_nb, host_copy_on=0 if world > 1 else None)
+    if gathered is None:
+        return []                                          # tracking, interpolation and the .trc files are rank 0's
+    Qk, ek, nk, mk = gathered
 
     Q_rows, e_rows, n_rows, m_rows = track_persons(Qk, ek, nk, mk, f_range, multi_person, max_distance_m, n_cams)
     index = range(*f_range)

@@ -5,7 +5,10 @@ inlier-camera selections (n_excl, excluded-camera mask, NaN pattern) -- checked 
   * the fixtures recorded from the reference (tests/golden/tri_units.npz),
   * the CPU oracle on fresh seeded inputs,
   * size-independent properties at BASELINE config sizes.
-The reprojection error leaves the kernel as float32: tolerance 2e-7 relative (one f32 ulp).
+The reprojection error leaves the kernel as float32: tolerance 2e-6 relative to max(1 px, err) -- float32 rounding
+(6e-8) plus what a 1e-9 m difference in Q moves a pixel error by (~3.5e-7 px at f/z ~ 350 px/m).
+Every test runs on both triangulation paths: the one-launch kernel with the in-wave subset search (the default where
+it applies: pinhole, no L/R swap, <= 16 cameras) and the streaming + work-list search pair.
 """
 import os
 
@@ -15,15 +18,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 TOL_Q = 1e-7        # metres
-TOL_E = 2e-6     # px, relative to max(1, err): a 1e-9 m change of Q moves a pixel error by ~3.5e-7 px (f/z ~ 350 px/m); err is a float32 output
+TOL_E = 2e-6        # px, relative to max(1, err)
 
 
-@pytest.fixture(scope='module')
-def engine():
+@pytest.fixture(scope='module', params=['auto', 'worklist'])
+def engine(request):
     import __graft_entry__ as entry
     entry.build_hip()
     from pose2sim_amd.engine import Engine
     eng = Engine(0)
+    eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST if request.param == 'worklist' else Engine.TRI_PATH_AUTO)
     yield eng
     eng.close()
 
@@ -49,13 +53,15 @@ def _compare(Q, err, nex, mask, Qr, er, nr, mr, what=''):
     ok = ~np.isnan(er)
     assert np.isnan(Q[~ok]).all()
     if ok.any():
-        # 1e-7 m inside a 10 m capture volume; beyond it the depth of a point seen under a vanishing angle is
-        # ill-posed in proportion to distance^2 / baseline (such points exist only as accepted garbage: two
-        # cameras, outliers that happen to agree), so the bound grows with (|Q| / 10 m)^2 there
-        scale = np.maximum(1.0, np.linalg.norm(Qr[ok], axis=1) / 10.0) ** 2
-        rel = np.abs(Q[ok] - Qr[ok]).max(axis=1) / scale
-        dq = rel.max()
-        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m (scaled beyond 10 m)'
+        # 1e-7 m inside a 10 m capture volume, 1e-8 relative beyond it.  The relative part is needed, and only by
+        # accepted garbage: with two cameras, noise can make two rays nearly parallel and the "point" lands 1.3 - 15 km
+        # away with a pixel error under the threshold (units 387186, 1417924, 1484274 of the two-camera test, measured
+        # |dQ| 1.6e-7 - 7.9e-7 m = 1e-11 - 6e-10 relative, on both kernel paths alike, exp/c2_far_units.py); at that
+        # depth the reference's own SVD is no better determined.  Every unit within 100 m of the origin, on every
+        # committed workload, is inside 1e-7 m unscaled (profiles/r02/sweep_tri.log: max 3.5e-9).
+        scale = np.maximum(1.0, np.linalg.norm(Qr[ok], axis=1) / 10.0)
+        dq = (np.abs(Q[ok] - Qr[ok]).max(axis=1) / scale).max()
+        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m (relative to max(10 m, |Q|) / 10 m)'
         de = np.abs(err[ok].astype(np.float64) - er[ok]) / np.maximum(1.0, np.abs(er[ok]))
         assert de.max() <= TOL_E, f'{what}: error differs by {de.max():.3e}'
         return dq
@@ -273,3 +279,69 @@ def test_many_cameras_every_unit_against_the_oracle(engine, name, F, C, min_cams
     Qr, er, nr, mr = tri_oracle.triangulate_batch(x64, wl['P'], wl['cams'] if undistort else None, swap, 0.3, 15.0, min_cams,
                                                   lr_swap, undistort, threads=threads)
     _compare(Q, err, nex, mask, Qr, er, nr, mr, name)
+
+
+def test_cfg4_shape_every_unit_against_the_oracle(engine):
+    """BASELINE configs[3]'s shape: 16 cameras x COCO_133 (131 keypoints in skeleton order), min_cameras = 3.
+    K = 131 makes the unit -> (block, keypoint) split, the 64-unit tiles and the 16-byte alignment of the wave-wide
+    result stores fall differently from K = 26; the frame counts give a last tile that is not full and (through a
+    second call on a slice that starts at an odd block) result pointers that are not 16-byte aligned."""
+    from oracle import tri_oracle
+    from pose2sim_amd import skeletons, synth
+    ids, names, swap = skeletons.keypoints('COCO_133')
+    K = len(ids)
+    assert K == 131
+    F, C = 9_001, 16
+    wl = synth.make_config(F, C, K, 1, seed=404, p_outlier=0.03, p_lowlik=0.05, p_missing_cam=0.01)
+    engine.set_calibration(wl['P'])
+    prm = engine.tri_params(15.0, 0.3, 3)
+    Q, err, nex, mask = engine.triangulate(wl['xyl'], prm)
+    threads = min(64, len(os.sched_getaffinity(0)))
+    Qr, er, nr, mr = tri_oracle.triangulate_batch(wl['xyl'].astype(np.float64), wl['P'], None, swap, 0.3, 15.0, 3, threads=threads)
+    _compare(Q, err, nex, mask, Qr, er, nr, mr, 'C=16 K=131 min_cams=3')
+    # odd first block, odd block count: the same numbers through the unaligned store path
+    Qs, es, ns, ms = engine.triangulate(wl['xyl'][1:778], prm)
+    assert np.array_equal(Qs, Q[1:778], equal_nan=True) and np.array_equal(es, err[1:778], equal_nan=True)
+    assert np.array_equal(ns, nex[1:778]) and np.array_equal(ms, mask[1:778])
+
+
+def test_unaligned_device_outputs(engine):
+    """p2s_triangulate_device with result pointers that are only element-aligned (the packed result buffer of a
+    caller need not start the float32 / uint32 / uint8 arrays on 16 bytes): same numbers as the aligned call.
+    Device memory comes from the HIP runtime directly (hipMalloc through ctypes), no torch in this process."""
+    import ctypes as C
+    from pose2sim_amd import synth
+    from pose2sim_amd.engine import P2S_F32
+    hip = C.CDLL('libamdhip64.so')
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    F, Cn, K = 333, 8, 26
+    wl = synth.make_config(F, Cn, K, 1, seed=77, p_outlier=0.05)
+    engine.set_calibration(wl['P'])
+    prm = engine.tri_params(15.0, 0.3, 2)
+    Q, err, nex, mask = engine.triangulate(wl['xyl'], prm)
+    n = F * K
+    xyl = np.ascontiguousarray(wl['xyl'])
+    d_x, d_o = C.c_void_p(), C.c_void_p()
+    total = n * 33 + 64
+    assert hip.hipMalloc(C.byref(d_x), xyl.nbytes) == 0 and hip.hipMalloc(C.byref(d_o), total) == 0
+    try:
+        assert hip.hipMemcpy(d_x, xyl.ctypes.data_as(C.c_void_p), xyl.nbytes, 1) == 0      # host -> device
+        assert hip.hipMemset(d_o, 0, total) == 0
+        base = d_o.value + 8                                       # Q 8-byte aligned only
+        pe, pm, px = base + n * 24, base + n * 28, base + n * 32 + 3
+        engine.triangulate_device(F, K, P2S_F32, d_x.value, None, prm, base, pe, px, pm)
+        engine.synchronize()
+        h = np.empty(total, dtype=np.uint8)
+        assert hip.hipMemcpy(h.ctypes.data_as(C.c_void_p), d_o, total, 2) == 0              # device -> host
+    finally:
+        hip.hipFree(d_x); hip.hipFree(d_o)
+    o = 8
+    Qd = h[o:o + n * 24].copy().view(np.float64).reshape(F, K, 3); o += n * 24
+    ed = h[o:o + n * 4].copy().view(np.float32).reshape(F, K); o += n * 4
+    md = h[o:o + n * 4].copy().view(np.uint32).reshape(F, K); o += n * 4
+    xd = h[o + 3:o + 3 + n].reshape(F, K)
+    assert np.array_equal(Qd, Q.reshape(F, K, 3), equal_nan=True) and np.array_equal(ed, err.reshape(F, K), equal_nan=True)
+    assert np.array_equal(md, mask.reshape(F, K)) and np.array_equal(xd, nex.reshape(F, K))
