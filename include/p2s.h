@@ -158,6 +158,25 @@ int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, con
                               const int64_t *offsets, const void *tracked, const p2s_single_params *params,
                               int32_t *comb, double *err, double *Q);
 
+/* ---- downstream of the .trc: filtering and quality metrics -----------------------------------
+ * Zero-phase Butterworth filter of every column of a row-major [n_frames][n_cols] float64 matrix: replaces
+ * Q_coords.apply(butterworth_filter_1d) in filter_all (filtering.py:437-471, 804): per column, every run of valid
+ * samples (not NaN, not 0) longer than padlen = 3 * n_coef goes through scipy.signal.filtfilt(b, a, run) (odd
+ * padding, steady-state initial conditions); other samples are copied.  b, a [n_coef] from
+ * scipy.signal.butter(order / 2, cutoff / (frame_rate / 2)) with a[0] = 1, zi [n_coef - 1] from
+ * scipy.signal.lfilter_zi(b, a); 2 <= n_coef <= 9.  All pointers are HOST pointers; the call blocks. */
+int p2s_butterworth_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_cols, const double *data, int32_t n_coef,
+                         const double *b, const double *a, const double *zi, double *out);
+/* trc_evaluate's per-frame quantities and sums (Utilities/trc_evaluate.py:114-238) for xyz [n_frames][n_markers][3]:
+ *   bones      [n_bones][2] int32  (parent, child) marker indices
+ *   bone_len   [n_bones][n_frames]      |child - parent|, 0 -> NaN             (compute_bone_lengths :135-139)
+ *   bone_stats [n_bones][3]             nanmean, nanstd (population), n_valid   (:141-150)
+ *   accel      [n_markers][n_frames-2]  |p[f+2] - 2 p[f+1] + p[f]|              (compute_smoothness :185-186)
+ *   missing    [n_markers] int64        frames with a NaN coordinate            (compute_missing_data :226-227)
+ * Medians / percentiles of accel stay with the caller (np.median, np.percentile).  HOST pointers; blocks. */
+int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, const double *xyz, int32_t n_bones,
+                         const int32_t *bones, double *bone_len, double *bone_stats, double *accel, int64_t *missing);
+
 /* Experiments and tests only -- nothing here changes a result, and the library never reads the environment.
  *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernel with the in-wave subset search where it
  *                         applies (pinhole, no L/R swap, <= 16 cameras), else the streaming + work-list search pair;

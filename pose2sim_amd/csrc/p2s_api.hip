@@ -672,6 +672,78 @@ int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, con
     return P2S_OK;
 }
 
+int p2s_butterworth_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_cols, const double *data, int32_t n_coef,
+                         const double *b, const double *a, const double *zi, double *out) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (n_frames < 0 || n_cols < 0) return fail(P2S_ERR_INVALID_ARG, "bad shape: n_frames=%lld n_cols=%d", (long long)n_frames, n_cols);
+    if (n_coef < 2 || n_coef > P2S_MAX_FILTER_ORDER + 1)
+        return fail(P2S_ERR_INVALID_ARG, "filter with %d coefficients: supported 2..%d", n_coef, P2S_MAX_FILTER_ORDER + 1);
+    if (n_frames == 0 || n_cols == 0) return P2S_OK;
+    if (!data || !out || !b || !a || !zi) return fail(P2S_ERR_INVALID_ARG, "null pointer");
+    if (!(a[0] == 1.0)) return fail(P2S_ERR_INVALID_ARG, "a[0] must be 1 (scipy.signal.butter normalises it)");
+    P2sFilterArgs f{};
+    f.n_frames = n_frames; f.n_cols = n_cols; f.n_order = n_coef - 1;
+    f.padlen = 3 * n_coef;                                  // filtering.py:457
+    for (int i = 0; i < n_coef; ++i) { f.b[i] = b[i]; f.a[i] = a[i]; }
+    for (int i = 0; i < n_coef - 1; ++i) f.zi[i] = zi[i];
+    const size_t bytes = (size_t)n_frames * n_cols * sizeof(double);
+    const size_t wbytes = (size_t)(n_frames + 2 * f.padlen) * n_cols * sizeof(double);
+    int rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.ensure(bytes)) != P2S_OK) return rc;
+    if ((rc = ctx->q.ensure(bytes)) != P2S_OK) return rc;
+    if ((rc = ctx->aux0.ensure(wbytes)) != P2S_OK) return rc;
+    f.in = (const double *)ctx->in.p; f.out = (double *)ctx->q.p; f.work = (double *)ctx->aux0.p;
+    HIP_TRY(hipMemcpyAsync(ctx->in.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(p2s_launch_butter(f, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->q.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
+int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, const double *xyz, int32_t n_bones,
+                         const int32_t *bones, double *bone_len, double *bone_stats, double *accel, int64_t *missing) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (n_frames < 0 || n_markers < 0 || n_bones < 0) return fail(P2S_ERR_INVALID_ARG, "bad shape");
+    if (n_frames == 0 || (n_markers == 0 && n_bones == 0)) return P2S_OK;
+    if (!xyz || (n_bones && (!bones || !bone_len || !bone_stats)) || (n_markers && (!accel || !missing)))
+        return fail(P2S_ERR_INVALID_ARG, "null pointer");
+    for (int i = 0; i < 2 * n_bones; ++i)
+        if (bones[i] < 0 || bones[i] >= n_markers) return fail(P2S_ERR_INVALID_ARG, "bone %d names marker %d of %d", i / 2, bones[i], n_markers);
+    const size_t xyz_b = (size_t)n_frames * n_markers * 3 * sizeof(double);
+    const size_t len_b = std::max<size_t>(16, (size_t)n_bones * n_frames * sizeof(double));
+    const size_t acc_b = std::max<size_t>(16, (size_t)n_markers * (n_frames > 2 ? n_frames - 2 : 0) * sizeof(double));
+    int rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.ensure(xyz_b)) != P2S_OK) return rc;
+    if ((rc = ctx->q.ensure(len_b)) != P2S_OK) return rc;
+    if ((rc = ctx->aux0.ensure(acc_b)) != P2S_OK) return rc;
+    if ((rc = ctx->aux1.ensure(std::max<size_t>(16, (size_t)n_bones * 8 + (size_t)n_bones * 24 + (size_t)n_markers * 8))) != P2S_OK) return rc;
+    P2sMetricsArgs m{};
+    m.xyz = (const double *)ctx->in.p;
+    m.bone_len = (double *)ctx->q.p;
+    m.accel = (double *)ctx->aux0.p;
+    unsigned char *aux = (unsigned char *)ctx->aux1.p;
+    m.bones = (const int32_t *)aux;
+    m.bone_stats = (double *)(aux + (size_t)n_bones * 8);
+    m.missing = (int64_t *)(aux + (size_t)n_bones * 8 + (size_t)n_bones * 24);
+    m.n_frames = n_frames; m.n_markers = n_markers; m.n_bones = n_bones;
+    HIP_TRY(hipMemcpyAsync(ctx->in.p, xyz, xyz_b, hipMemcpyHostToDevice, ctx->stream));
+    if (n_bones) HIP_TRY(hipMemcpyAsync(aux, bones, (size_t)n_bones * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(p2s_launch_trc_metrics(m, ctx->stream));
+    if (n_bones) {
+        HIP_TRY(hipMemcpyAsync(bone_len, m.bone_len, (size_t)n_bones * n_frames * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(bone_stats, m.bone_stats, (size_t)n_bones * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n_markers) {
+        if (n_frames > 2)
+            HIP_TRY(hipMemcpyAsync(accel, m.accel, (size_t)n_markers * (n_frames - 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(missing, m.missing, (size_t)n_markers * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
 int p2s_timing_begin(p2s_ctx *ctx) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -1,0 +1,182 @@
+// p2s_filter.hip -- zero-phase Butterworth filtering of .trc coordinate columns and the trc_evaluate quality metrics
+// on gfx950 (the first consumer of the triangulation's output).
+//
+// p2s_butter_kernel: filtering.py:437-471 (butterworth_filter_1d) for every column at once.  A column is cut into its
+// runs of valid samples (not NaN, not 0); a run longer than padlen goes through scipy.signal.filtfilt's algorithm
+// (odd extension by padlen samples at either end, forward pass of the IIR filter in direct form II transposed with
+// the steady-state initial condition scaled by the first sample, backward pass likewise, extension dropped), every
+// other sample is copied.  The recurrence is sequential in time, so the parallel axis is the column: one lane per
+// column, consecutive lanes = consecutive columns of the row-major [frame][column] matrix, i.e. coalesced loads
+// while the columns' runs coincide (they do after triangulate_all's gap filling).  Latency-bound on the recurrence
+// (2 passes x ~6 dependent fp64 operations per sample): a few ms for 100k frames, whatever the number of columns up
+// to the chip's 16k resident lanes; HBM traffic is 5 x 8 B per sample and irrelevant.
+//
+// p2s_trc_metrics_kernel: Utilities/trc_evaluate.py:114-228 -- per-frame bone lengths and second-difference
+// magnitudes written out for the host's order statistics, sums for means and standard deviations, missing counts.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "p2s_internal.h"
+
+namespace {
+
+__device__ __forceinline__ bool sample_valid(double v) { return (v == v) && (v != 0.0); }
+
+// One sample of scipy's lfilter (direct form II transposed, a[0] = 1): y = z[0] + b[0] x, then
+// z[k] = z[k+1] + b[k+1] x - a[k+1] y.  Same operation order as scipy's C loop and no contraction, so that the result
+// matches scipy.signal.filtfilt to rounding.
+template <int N>
+__device__ __forceinline__ double iir_step(const P2sFilterArgs &a, double (&z)[N], double x) {
+#pragma clang fp contract(off)
+    const double y = z[0] + a.b[0] * x;
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) z[k] = (z[k + 1] + x * a.b[k + 1]) - y * a.a[k + 1];
+    z[N - 1] = x * a.b[N] - y * a.a[N];
+    return y;
+}
+
+template <int N>
+__global__ void __launch_bounds__(64) p2s_butter_kernel(const P2sFilterArgs a) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= a.n_cols) return;
+    const int64_t F = a.n_frames, S = a.n_cols;
+    const double *in = a.in + col;
+    double *out = a.out + col;
+    double *work = a.work + col;
+    const int64_t pad = a.padlen;
+    int64_t f = 0;
+    while (f < F) {
+        const double v = in[f * S];
+        if (!sample_valid(v)) { out[f * S] = v; ++f; continue; }
+        int64_t r = f + 1;                                     // the run [f, r) of valid samples
+        while (r < F && sample_valid(in[r * S])) ++r;
+        const int64_t L = r - f;
+        if (L <= pad) {                                        // filtering.py:466: only runs longer than padlen
+            for (int64_t i = f; i < r; ++i) out[i * S] = in[i * S];
+            f = r;
+            continue;
+        }
+        // scipy.signal.filtfilt(b, a, x) with its defaults: padtype 'odd', padlen = 3 max(len(a), len(b))
+        const double *x = in + f * S;
+        const double x0 = x[0], xl = x[(L - 1) * S];
+        const int64_t E = L + 2 * pad;
+        auto ext = [&](int64_t i) -> double {
+            if (i < pad) return 2.0 * x0 - x[(pad - i) * S];
+            if (i < pad + L) return x[(i - pad) * S];
+            return 2.0 * xl - x[(L - 2 - (i - pad - L)) * S];
+        };
+        double z[N];
+        const double e0 = ext(0);
+#pragma unroll
+        for (int k = 0; k < N; ++k) z[k] = a.zi[k] * e0;
+        for (int64_t i = 0; i < E; ++i) work[i * S] = iir_step<N>(a, z, ext(i));
+        const double y0 = work[(E - 1) * S];
+#pragma unroll
+        for (int k = 0; k < N; ++k) z[k] = a.zi[k] * y0;
+        for (int64_t i = E - 1; i >= 0; --i) {
+            const double y = iir_step<N>(a, z, work[i * S]);
+            if (i >= pad && i < pad + L) out[(f + i - pad) * S] = y;
+        }
+        f = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// trc_evaluate: one workgroup per bone (blocks [0, n_bones)) or per marker (blocks [n_bones, n_bones + n_markers)).
+__global__ void __launch_bounds__(256) p2s_trc_metrics_kernel(const P2sMetricsArgs a) {
+    __shared__ double s_sum[256];
+    __shared__ unsigned long long s_cnt[256];
+    const int tid = threadIdx.x;
+    const int64_t F = a.n_frames;
+    const int K = a.n_markers;
+    if ((int)blockIdx.x < a.n_bones) {
+        // compute_bone_lengths (:114-156): |child - parent| per frame, 0 -> NaN; mean and population standard deviation
+        // of the valid lengths (two passes over the frames: the deviations are taken from the final mean, as np.nanstd)
+        const int bi = blockIdx.x;
+        const int p = a.bones[2 * bi], c = a.bones[2 * bi + 1];
+        double *len = a.bone_len + (int64_t)bi * F;
+        double sum = 0.0;
+        unsigned long long cnt = 0;
+        for (int64_t f = tid; f < F; f += 256) {
+            const double *P = a.xyz + (f * K + p) * 3, *C = a.xyz + (f * K + c) * 3;
+            const double dx = C[0] - P[0], dy = C[1] - P[1], dz = C[2] - P[2];
+            double l = sqrt(dx * dx + dy * dy + dz * dz);
+            if (l == 0.0) l = __builtin_nan("");
+            len[f] = l;
+            if (l == l) { sum += l; ++cnt; }
+        }
+        s_sum[tid] = sum; s_cnt[tid] = cnt;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) { s_sum[tid] += s_sum[tid + o]; s_cnt[tid] += s_cnt[tid + o]; }
+            __syncthreads();
+        }
+        const unsigned long long n = s_cnt[0];
+        const double mean = n ? s_sum[0] / (double)n : __builtin_nan("");
+        __syncthreads();
+        double dev = 0.0;
+        for (int64_t f = tid; f < F; f += 256) {
+            const double l = len[f];
+            if (l == l) dev += (l - mean) * (l - mean);
+        }
+        s_sum[tid] = dev;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_sum[tid] += s_sum[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.bone_stats[3 * bi + 0] = mean;
+            a.bone_stats[3 * bi + 1] = n ? sqrt(s_sum[0] / (double)n) : __builtin_nan("");
+            a.bone_stats[3 * bi + 2] = (double)n;
+        }
+        return;
+    }
+    // compute_smoothness (:159-207) and compute_missing_data (:210-238) of one marker
+    const int m = blockIdx.x - a.n_bones;
+    if (m >= K) return;
+    double *acc = a.accel + (int64_t)m * (F > 2 ? F - 2 : 0);
+    unsigned long long missing = 0;
+    for (int64_t f = tid; f < F; f += 256) {
+        const double *p0 = a.xyz + (f * K + m) * 3;
+        if (!(p0[0] == p0[0]) || !(p0[1] == p0[1]) || !(p0[2] == p0[2])) ++missing;
+        if (f + 2 < F) {
+            const double *p1 = p0 + (int64_t)K * 3, *p2 = p1 + (int64_t)K * 3;
+            const double ax = p2[0] - 2 * p1[0] + p0[0], ay = p2[1] - 2 * p1[1] + p0[1], az = p2[2] - 2 * p1[2] + p0[2];
+            acc[f] = sqrt(ax * ax + ay * ay + az * az);
+        }
+    }
+    s_cnt[tid] = missing;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_cnt[tid] += s_cnt[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) a.missing[m] = (int64_t)s_cnt[0];
+}
+
+}  // namespace
+
+hipError_t p2s_launch_butter(const P2sFilterArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.n_cols + 63) / 64);
+    switch (a.n_order) {
+    case 1: hipLaunchKernelGGL((p2s_butter_kernel<1>), dim3(grid), dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((p2s_butter_kernel<2>), dim3(grid), dim3(64), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((p2s_butter_kernel<3>), dim3(grid), dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((p2s_butter_kernel<4>), dim3(grid), dim3(64), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((p2s_butter_kernel<5>), dim3(grid), dim3(64), 0, s, a); break;
+    case 6: hipLaunchKernelGGL((p2s_butter_kernel<6>), dim3(grid), dim3(64), 0, s, a); break;
+    case 7: hipLaunchKernelGGL((p2s_butter_kernel<7>), dim3(grid), dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((p2s_butter_kernel<8>), dim3(grid), dim3(64), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t p2s_launch_trc_metrics(const P2sMetricsArgs &a, hipStream_t s) {
+    const unsigned grid = (unsigned)(a.n_bones + a.n_markers);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(p2s_trc_metrics_kernel, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}

@@ -97,4 +97,28 @@ hipError_t p2s_launch_single(const P2sSingleArgs &a, int dtype, hipStream_t s);
 
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s);
 
+// p2s_filter.hip
+#define P2S_MAX_FILTER_ORDER 8
+struct P2sFilterArgs {
+    const double *in;            // [n_frames][n_cols]
+    double *out;                 // [n_frames][n_cols]
+    double *work;                // [n_frames + 2 padlen][n_cols] forward-pass output
+    int64_t n_frames;
+    int32_t n_cols, n_order, padlen;   // n_order = len(b) - 1
+    double b[P2S_MAX_FILTER_ORDER + 1], a[P2S_MAX_FILTER_ORDER + 1], zi[P2S_MAX_FILTER_ORDER];
+};
+hipError_t p2s_launch_butter(const P2sFilterArgs &a, hipStream_t s);
+
+struct P2sMetricsArgs {
+    const double *xyz;           // [n_frames][n_markers][3]
+    const int32_t *bones;        // [n_bones][2] (parent, child) marker indices
+    double *bone_len;            // [n_bones][n_frames]
+    double *bone_stats;          // [n_bones][3] mean, population sd, n_valid
+    double *accel;               // [n_markers][n_frames - 2]
+    int64_t *missing;            // [n_markers]
+    int64_t n_frames;
+    int32_t n_markers, n_bones;
+};
+hipError_t p2s_launch_trc_metrics(const P2sMetricsArgs &a, hipStream_t s);
+
 #endif

@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kSlots = 28;                 // units a wave searches at a time (more: further rounds)
 constexpr uint32_t kNone = 0xffffffffu;
+constexpr int kSubLds = 256;               // subset-table entries kept in LDS
 
 // A searching unit's state in LDS: what the lanes of its group need (normal matrix, masks, the lane that holds its
 // observations in the wave's staging arrays) and the result of the level just finished (written by the winning lane
@@ -74,6 +75,45 @@ __device__ __forceinline__ void load_observations(const P2sTriArgs &a, int C, ui
     }
 }
 
+// Mean reprojection error over the cameras of `kept` (triangulation.py:472-489, common.py:357-403), pinhole model, with
+// the projection matrices read from LDS: as VGPR operands they need none of the v_mov a second SGPR operand of an
+// fp64 FMA costs on gfx950 (one constant-bus read per instruction: 6 moves per camera), and LDS reads return in
+// order, so the next camera's matrix is in flight while this one is used (scalar loads return out of order and each
+// one drains the queue).  Degenerate or NaN operands take camera_distance_exact as in mean_error.
+template <int CT, typename OBS>
+__device__ __forceinline__ double mean_error_lds(const double *sP, cam_cptr cams, int C, const OBS &o, uint32_t kept,
+                                                 const double q[3]) {
+    double sum = 0.0;
+    bool irregular = false;
+    for_each_cam<CT>(C, [&](int c) {
+        double x, y, w;
+        o.raw(c, x, y, w);
+        const double *P = sP + c * 12;
+        const double a = fma(P[0], q[0], fma(P[1], q[1], fma(P[2], q[2], P[3])));
+        const double b = fma(P[4], q[0], fma(P[5], q[1], fma(P[6], q[2], P[7])));
+        const double z = fma(P[8], q[0], fma(P[9], q[1], fma(P[10], q[2], P[11])));
+        const double dxz = fma(-x, z, a), dyz = fma(-y, z, b);
+        const double s = fma(dxz, dxz, dyz * dyz);
+        const double t = s * z * z;
+        const bool reg = (t > 0.0) && (t < kInf);
+        const double d = s * fast_rsqrt(t);
+        const bool k = (kept >> c) & 1u;
+        irregular = irregular || (k && !reg);
+        sum += k ? d : 0.0;
+    });
+    if (__any(irregular)) {                        // rare: some wanted camera is degenerate / NaN
+        double sum2 = 0.0;
+        for_each_cam<CT>(C, [&](int c) {
+            double x, y, w;
+            o.raw(c, x, y, w);
+            const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], x, y);
+            sum2 += ((kept >> c) & 1u) ? d : 0.0;
+        });
+        sum = irregular ? sum2 : sum;
+    }
+    return sum * fast_rcp((double)__popc(kept));   // no camera kept -> NaN, as np.mean([])
+}
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -91,6 +131,8 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
     __shared__ __align__(16) unsigned char smem[sizeof(slot_t) * kSlots];
     __shared__ __align__(16) double sP[CT * 12];
     __shared__ uint32_t sList[kSlots];
+    __shared__ uint16_t sSub[kSubLds];         // head of the subset table (all of it up to 8 cameras): a global load per
+                                               // evaluation pass would stall the wave for an L2 round trip
     // results of the wave's 64 units, staged for the 16-byte stores at the end; they are parked here before the search
     // (instead of in 10 registers per lane across it) and the searching units overwrite theirs level by level
     __shared__ __align__(16) double sQ[64 * 3];
@@ -121,6 +163,11 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
     RegObs<T, CT> obs;
     obs.lik_thr = a.lik_thr;
     load_observations<T, CT, EXACT>(a, C, b, k, obs);
+    for (int i = lane; i < C * 12; i += 64) sP[i] = a.cams[i / 12].P[i % 12];
+    {
+        const int n_sub = min(kSubLds, (int)a.sub_off[C + 1]);
+        for (int i = lane; i < n_sub; i += 64) sSub[i] = a.sub_tab[i];
+    }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         sXY[c][lane][0] = obs.x[c]; sXY[c][lane][1] = obs.y[c];
@@ -147,7 +194,8 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
         double q[3];
         smallest_eigvec(N, q);
         if (nvalid < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }   // common.py:347: fewer than 4 rows
-        const double e = mean_error<T, false, CT>(cams, C, obs, valid, q);
+        wave_sync();                                           // sP, and the staged observations for the search
+        const double e = mean_error_lds<CT>(sP, cams, C, obs, valid, q);
         const bool ran = Lmax >= 0;                            // else no level completes: inf, all cameras (:595-596)
         const bool ok = ran && (e <= thr);                     // :600-602
         sQ[lane * 3 + 0] = ok ? q[0] : d_nan();
@@ -162,7 +210,6 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
     // ---- camera-subset search, in this wave ---------------------------------------------------------------------------
     const unsigned long long hard = __ballot(need);
     if (hard != 0ull) {
-        for (int i = lane; i < C * 12; i += 64) sP[i] = a.cams[i / 12].P[i % 12];
         const unsigned long long lt = (1ull << lane) - 1ull;
         const int n_hard = __popcll(hard);
         const int my_ord = __popcll(hard & lt);
@@ -200,8 +247,8 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                 const int npend = __popcll(pend);
                 if (cont) sList[__popcll(pend & lt)] = (uint32_t)my_slot;
                 wave_sync();
-                const uint32_t nsub = a.sub_off[level + 1] - a.sub_off[level];
-                const uint16_t *subs = a.sub_tab + a.sub_off[level];
+                const uint32_t sub0 = a.sub_off[level];
+                const uint32_t nsub = a.sub_off[level + 1] - sub0;
                 // lanes per unit for this level: the power of two that needs the fewest
                 // (passes over the pending units) x (rounds over the level's subsets)
                 int lg = 2;
@@ -231,7 +278,7 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                         bool go = has && (r < nsub);
                         uint32_t S = 0;
                         if (go) {
-                            S = subs[r];
+                            S = (sub0 + r < (uint32_t)kSubLds) ? sSub[sub0 + r] : a.sub_tab[sub0 + r];
                             // duplicates of one effective configuration (quirk Q1: a subset that "removes" cameras which
                             // are out already) carry identical numbers; only the lexicographically first one -- its
                             // padding is the LOWEST cameras of the excluded set -- can win the argmin
@@ -261,7 +308,7 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                         // them into VGPR lanes and pays a v_readlane per operand)
                         cam_cptr cams_here = cams;
                         asm volatile("" : "+s"(cams_here));
-                        const double e = mean_error<T, false, CT>(cams_here, C, sobs, kept, q);
+                        const double e = mean_error_lds<CT>(sP, cams_here, C, sobs, kept, q);
                         if (go && (e < be || brank == kNone)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
                     }
                     // group argmin, first (lowest-rank) index on ties (np.nanargmin, :502): what the group's first lane

@@ -172,6 +172,38 @@ class Engine:
         _lib.check(self._lib.p2s_tri_geometry(self.n_cams, int(K), int(dtype), C.byref(fb), C.byref(th), C.byref(lds)))
         return {'blocks_per_tile': fb.value, 'threads': th.value, 'lds_bytes': lds.value}
 
+    # -- downstream of the .trc -----------------------------------------
+    def butterworth(self, data, b, a, zi):
+        """Zero-phase Butterworth filter of every column of data [n_frames][n_cols] (filtering.py:437-471)."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.ndim != 2:
+            raise P2sError(f'data has shape {data.shape}; expected [n_frames][n_cols]')
+        b = np.ascontiguousarray(b, dtype=np.float64); a = np.ascontiguousarray(a, dtype=np.float64)
+        zi = np.ascontiguousarray(zi, dtype=np.float64)
+        if len(a) != len(b) or len(zi) != len(b) - 1:
+            raise P2sError('b, a and zi must have n, n and n - 1 coefficients')
+        out = np.empty_like(data)
+        _lib.check(self._lib.p2s_butterworth_host(self._h, data.shape[0], data.shape[1], _ptr(data) if data.size else None,
+                                                  len(b), _ptr(b), _ptr(a), _ptr(zi), _ptr(out) if out.size else None))
+        return out
+
+    def trc_metrics(self, xyz, bones):
+        """trc_evaluate's per-frame quantities for xyz [F][K][3] and bones [n][2] (parent, child marker indices):
+        bone_len [n][F], bone_stats [n][3] (mean, population sd, n_valid), accel [K][F-2], missing [K]."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+        if xyz.ndim != 3 or xyz.shape[2] != 3:
+            raise P2sError(f'xyz has shape {xyz.shape}; expected [F][K][3]')
+        bones = np.ascontiguousarray(np.asarray(bones, dtype=np.int32).reshape(-1, 2))
+        F, K = xyz.shape[:2]
+        nb = bones.shape[0]
+        bone_len = np.full((nb, F), np.nan)
+        bone_stats = np.full((nb, 3), np.nan)
+        accel = np.full((K, max(F - 2, 0)), np.nan)
+        missing = np.zeros(K, dtype=np.int64)
+        p = lambda x: _ptr(x) if x.size else None                           # noqa: E731
+        _lib.check(self._lib.p2s_trc_metrics_host(self._h, F, K, p(xyz), nb, p(bones), p(bone_len), p(bone_stats), p(accel), p(missing)))
+        return bone_len, bone_stats, accel, missing
+
     # -- association -----------------------------------------------------------------------
     @staticmethod
     def assoc_params(recon_thr, min_affinity, min_cams, max_iter=20, w_rank=50.0, tol=1e-4, w_sparse=0.1):

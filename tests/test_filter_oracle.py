@@ -1,0 +1,128 @@
+"""Filtering stage and trc_evaluate on CPU: the oracle (oracle/filtering_ref.py) against the goldens recorded from the
+reference (tests/golden/filter_units.npz <- make_golden_filter.py), and the host mirror (pose2sim_amd/filtering.py,
+trc_evaluate.py) with an oracle-backed test double standing in for the HIP engine: the .trc file it writes must equal
+the reference's byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import filtering_ref as fr
+
+
+class OracleFilterEngine:
+    """Test double of Engine.butterworth / Engine.trc_metrics (no GPU in this container)."""
+
+    def butterworth(self, data, b, a, zi):
+        from scipy import signal
+        data = np.asarray(data, dtype=np.float64)
+        out = data.copy()
+        padlen = 3 * max(len(a), len(b))
+        for c in range(data.shape[1]):
+            col = out[:, c]
+            good = np.where(~(np.isnan(col) | (col == 0)))[0]
+            for seq in np.split(good, np.where(np.diff(good) > 1)[0] + 1):
+                if len(seq) > padlen:
+                    col[seq] = signal.filtfilt(b, a, col[seq])
+        return out
+
+    def trc_metrics(self, xyz, bones):
+        stats, lens = fr.bone_lengths(xyz, [tuple(b) for b in bones])
+        F, K = xyz.shape[:2]
+        accel = np.full((K, max(F - 2, 0)), np.nan)
+        if F >= 3:
+            for m in range(K):
+                accel[m] = np.linalg.norm(xyz[2:, m] - 2 * xyz[1:-1, m] + xyz[:-2, m], axis=1)
+        missing = np.array([m[1] for m in fr.missing_data(xyz)], dtype=np.int64)
+        return lens, np.array([[s[0], s[1], s[3]] for s in stats]).reshape(len(bones), 3), accel, missing
+
+
+@pytest.fixture(scope='module')
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, 'filter_units.npz'))
+
+
+def test_oracle_columns_match_the_reference(gold):
+    for i in range(int(gold['n_cols'])):
+        order, cutoff, rate = (int(v) for v in gold[f'col{i}_prm'])
+        got = fr.butterworth_filter_1d(gold[f'col{i}_in'], order, cutoff, rate)
+        assert np.array_equal(got, gold[f'col{i}_out'], equal_nan=True), i
+
+
+def test_coefficients_are_the_reference_calls():
+    from scipy import signal
+    from pose2sim_amd import filtering
+    b, a, zi = filtering.butterworth_coefficients(4, 6, 60)
+    rb, ra = signal.butter(2.0, 6 / 30.0, 'low', analog=False)
+    assert np.array_equal(b, rb) and np.array_equal(a, ra) and a[0] == 1.0
+    assert np.array_equal(zi, signal.lfilter_zi(rb, ra)) and len(zi) == len(b) - 1
+
+
+@pytest.fixture
+def work_dir():
+    """A scratch directory whose path does not contain 'filt': the reference skips every .trc whose PATH does
+    (filtering.py:777), and pytest's tmp_path is named after the test."""
+    import shutil
+    import tempfile
+    from pathlib import Path
+    d = tempfile.mkdtemp(prefix='p2s_bw_')
+    yield Path(d)
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _write_trial(tmp_path, gold, i):
+    trial = tmp_path / f'trial{i}'
+    (trial / 'pose-3d').mkdir(parents=True)
+    (trial / 'pose-3d' / str(gold[f'file{i}_name'])).write_text(str(gold[f'file{i}_text']))
+    order, cutoff, rate = (int(v) for v in gold[f'file{i}_prm'])
+    cfg = {'project': {'project_dir': str(trial), 'frame_rate': rate, 'frame_range': 'auto'}, 'pose': {'vid_img_extension': 'mp4'},
+           'filtering': {'type': 'butterworth', 'filter': True, 'reject_outliers': False,
+                         'butterworth': {'order': order, 'cut_off_frequency': cutoff}}}
+    return trial, cfg
+
+
+def test_filter_all_writes_the_reference_file(work_dir, gold):
+    tmp_path = work_dir
+    from pose2sim_amd import filtering
+    for i in range(int(gold['n_files'])):
+        trial, cfg = _write_trial(tmp_path, gold, i)
+        paths = filtering.filter_all(cfg, engine=OracleFilterEngine())
+        assert [os.path.basename(p) for p in paths] == [str(gold[f'file{i}_out_name'])]
+        assert open(paths[0]).read() == str(gold[f'file{i}_out_text'])
+
+
+def test_other_filter_types_are_refused(work_dir, gold):
+    tmp_path = work_dir
+    from pose2sim_amd import filtering
+    trial, cfg = _write_trial(tmp_path, gold, 0)
+    cfg['filtering']['type'] = 'kalman'
+    with pytest.raises(NotImplementedError):
+        filtering.filter_all(cfg, engine=OracleFilterEngine())
+
+
+def _check_evaluation(ev, gold, pre):
+    assert [b['name'] for b in ev['bone_results']] == [str(s) for s in gold[pre + 'bone_names']]
+    got = np.array([[b['mean'], b['sd'], b['cv'], b['n_valid']] for b in ev['bone_results']], dtype=np.float64)
+    np.testing.assert_allclose(got, gold[pre + 'bones'], rtol=1e-12, atol=0, equal_nan=True)
+    got = np.array([[s['accel_median'], s['accel_p95'], s['accel_median_si'], s['accel_p95_si'], s['n_valid']] for s in ev['smooth_results']])
+    np.testing.assert_allclose(got, gold[pre + 'smooth'], rtol=1e-12, atol=0, equal_nan=True)
+    got = np.array([[m['n_total'], m['n_missing'], m['missing_pct']] for m in ev['missing_results']], dtype=np.float64)
+    np.testing.assert_allclose(got, gold[pre + 'missing'], rtol=1e-15, equal_nan=True)
+    assert [s['pair_name'] for s in ev['symmetry_results']] == [str(s) for s in gold[pre + 'sym_names']]
+    got = np.array([[s['left_mean'], s['right_mean'], s['diff_pct']] for s in ev['symmetry_results']])
+    np.testing.assert_allclose(got, gold[pre + 'sym'], rtol=1e-11, equal_nan=True)
+    sm = ev['summary']
+    np.testing.assert_allclose([sm['mean_cv'], sm['worst_cv'], sm['mean_accel_p95'], sm['overall_nan_pct'], sm['mean_lr_diff']],
+                               gold[pre + 'summary'], rtol=1e-11, equal_nan=True)
+    assert sm['worst_bone'] == str(gold[pre + 'worst'])
+
+
+def test_trc_evaluate_matches_the_reference(tmp_path, gold):
+    from pose2sim_amd import trc_evaluate
+    for i in range(int(gold['n_files'])):
+        for tag, name, text in (('raw', gold[f'file{i}_name'], gold[f'file{i}_text']),
+                                ('filt', gold[f'file{i}_out_name'], gold[f'file{i}_out_text'])):
+            p = tmp_path / f'{i}_{tag}_{name}'
+            p.write_text(str(text))
+            ev = trc_evaluate.evaluate_single(str(p), engine=OracleFilterEngine())
+            _check_evaluation(ev, gold, f'file{i}_{tag}_')
