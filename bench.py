@@ -47,9 +47,13 @@ CONFIGS = {
     'cfg4': dict(workload='synthetic 16-cam x COCO_133 (131 kpts) x 125k frames/GPU, min_cameras=3 (BASELINE configs[3] shard)',
                  F=125_000, C=16, model='COCO_133', Pn=1, thr=15.0, lik=0.3, min_cams=3,
                  undistort=False, lr_swap=False, seed=4),
-    # per-GPU shard of BASELINE configs[4] (10M frames over 8 GPUs), reduced 10x to keep host generation short
-    'cfg5': dict(workload='synthetic 32-cam x HALPE_26 x 125k frames/GPU, undistort + LR swap (BASELINE configs[4] shard, 1/10 length)',
-                 F=125_000, C=32, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
+    # per-GPU shard of BASELINE configs[4] (10M frames over 8 GPUs): 1.25 M frames = 12.5 GB of observations per GPU
+    # the same at 1/10 length (quick runs of the search-bound 32-camera path)
+    'cfg5_tenth': dict(workload='synthetic 32-cam x HALPE_26 x 125k frames/GPU, undistort + LR swap (BASELINE configs[4] shard, 1/10 length)',
+                       F=125_000, C=32, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
+                       undistort=True, lr_swap=True, seed=5),
+    'cfg5': dict(workload='synthetic 32-cam x HALPE_26 x 1.25M frames/GPU, undistort + LR swap (BASELINE configs[4] shard, full length)',
+                 F=1_250_000, C=32, model='HALPE_26', Pn=1, thr=15.0, lik=0.3, min_cams=2,
                  undistort=True, lr_swap=True, seed=5),
 }
 
@@ -237,35 +241,84 @@ def bench_single(args, cfg, rank, world, local_rank):
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(cfg, xyl, cams, P, swap, budget_frames):
-    """The CPU oracle (a loop-faithful NumPy port of the reference) on the first frames."""
+def _oracle_slice(args):
+    """Worker of the process-parallel CPU baseline: the NumPy oracle on one block of frames."""
+    xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort = args
     from oracle import triangulation_ref as tr
-    n = min(budget_frames, xyl.shape[0])
-    t0 = time.perf_counter()
-    tr.triangulate_batch(xyl[:n], P, cams, list(swap), cfg['lik'], cfg['thr'], cfg['min_cams'],
-                         cfg['lr_swap'], cfg['undistort'])
-    dt = time.perf_counter() - t0
-    units = n * xyl.shape[1] * xyl.shape[3]
-    return {'value': units / dt, 'unit': 'keypoint-triangulations/s', 'cores': 1, 'kind': 'port',
-            'sample': f'first {n} frames of the same workload ({units} units, {dt:.1f} s), NumPy oracle, arithmetic only'}
+    tr.triangulate_batch(xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort)
+    return xyl.shape[0]
 
 
-def cpu_baseline_native(cfg, xyl, cams, P, swap, budget_frames):
-    """The same algorithm in C with OpenMP (oracle/tri_oracle.c, parity-checked against the goldens) on all
-    the host cores this process may use: what a compiled CPU implementation of the reference would reach."""
-    from oracle import tri_oracle
+def host_sample(cfg, n_frames):
+    """A bounded slice of the same workload from the host generator (the oracle needs host arrays)."""
+    from pose2sim_amd import skeletons, synth
+    ids, names, swap = skeletons.keypoints(cfg['model'])
+    gen = dict(cfg.get('gen', {}))
+    cams = synth.make_cameras(cfg['C'], seed=cfg['seed'], distort=cfg['undistort'])
+    Q3d = synth.make_points3d(n_frames, cfg['Pn'], len(ids), seed=cfg['seed'])
+    xyl = synth.make_observations(Q3d, cams, seed=cfg['seed'], distort=cfg['undistort'],
+                                  p_lr_swap=0.02 if cfg['lr_swap'] else 0.0, swap_idx=swap, **gen)
+    return xyl, cams, synth.projection_matrices(cams, cfg['undistort']), list(swap)
+
+
+def cpu_baselines(cfg, frames_1core, frames_all):
+    """the NumPy oracle (loop-faithful port of the reference, parity-checked against the goldens) on a
+    bounded slice of the workload, arithmetic only: single process on one core, and process-parallel over frames on
+    all the host cores this process may use.  Plus the same algorithm in C + OpenMP (oracle/tri_oracle.c) on all
+    cores: what a compiled CPU implementation would reach.  Runs BEFORE anything touches the GPU (fork)."""
+    import multiprocessing as mp
+    from oracle import triangulation_ref as tr
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    n = min(budget_frames, xyl.shape[0])
-    x = np.ascontiguousarray(xyl[:n], dtype=np.float64)
-    tri_oracle.triangulate_batch(x[:64], P, cams, list(swap), cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'],
-                                 cfg['undistort'], threads=cores)          # thread pool start-up outside the timing
+    xyl, cams, P, swap = host_sample(cfg, max(frames_1core, frames_all))
+    per_frame = xyl.shape[1] * xyl.shape[3]
+    out = {}
     t0 = time.perf_counter()
-    tri_oracle.triangulate_batch(x, P, cams, list(swap), cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'],
-                                 cfg['undistort'], threads=cores)
+    tr.triangulate_batch(xyl[:frames_1core], P, cams, swap, cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'], cfg['undistort'])
     dt = time.perf_counter() - t0
-    units = n * xyl.shape[1] * xyl.shape[3]
-    return {'value': units / dt, 'unit': 'keypoint-triangulations/s', 'cores': cores, 'kind': 'port',
-            'sample': f'first {n} frames of the same workload ({units} units, {dt:.1f} s), C + OpenMP oracle, arithmetic only'}
+    out['cpu_baseline_1core'] = {'value': frames_1core * per_frame / dt, 'unit': 'keypoint-triangulations/s', 'cores': 1, 'kind': 'port',
+                                 'sample': f'first {frames_1core} frames of the same workload ({frames_1core * per_frame} units, {dt:.1f} s), NumPy oracle, arithmetic only'}
+    workers = max(1, min(cores, frames_all))
+    bounds = np.linspace(0, frames_all, workers + 1).astype(int)
+    jobs = [(xyl[a:b], P, cams, swap, cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'], cfg['undistort'])
+            for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    with mp.get_context('fork').Pool(workers) as pool:
+        pool.map(_oracle_slice, [(j[0][:1],) + j[1:] for j in jobs])           # start-up and imports outside the timing
+        t0 = time.perf_counter()
+        pool.map(_oracle_slice, jobs, chunksize=1)
+        dt = time.perf_counter() - t0
+    out['cpu_baseline'] = {'value': frames_all * per_frame / dt, 'unit': 'keypoint-triangulations/s', 'cores': workers, 'kind': 'port',
+                           'sample': f'first {frames_all} frames of the same workload ({frames_all * per_frame} units, {dt:.1f} s), NumPy oracle, '
+                                     f'{workers} processes over frames, arithmetic only'}
+    try:
+        from oracle import tri_oracle
+        n = frames_all * (50 if cfg['C'] <= 8 else 5)
+        x, cams2, P2, swap2 = host_sample(cfg, n) if n > xyl.shape[0] else (xyl, cams, P, swap)
+        x = np.ascontiguousarray(x[:n], dtype=np.float64)
+        tri_oracle.triangulate_batch(x[:64], P2, cams2, swap2, cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'], cfg['undistort'], threads=cores)
+        t0 = time.perf_counter()
+        tri_oracle.triangulate_batch(x, P2, cams2, swap2, cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'], cfg['undistort'], threads=cores)
+        dt = time.perf_counter() - t0
+        out['cpu_baseline_native'] = {'value': n * per_frame / dt, 'unit': 'keypoint-triangulations/s', 'cores': cores, 'kind': 'port',
+                                      'sample': f'first {n} frames of the same workload ({n * per_frame} units, {dt:.1f} s), C + OpenMP oracle, arithmetic only'}
+    except Exception as e:                         # the C oracle is optional test infrastructure
+        out['cpu_baseline_native'] = {'error': str(e)}
+    return out
+
+
+# fp64 operations of the path, counted from the kernels' arithmetic (an FMA = 2): the normal-matrix contribution of one
+# camera (18 multiply / FMA for the two weighted rows, 20 FMA for the rank-2 update of the 10 entries), the eigen-solve
+# (first pass ~95, later passes ~115 at 1.1 later passes on average), the reprojection distance of one camera
+# (9 FMA projection, 4 FMA / multiply residuals, 2 for s z^2, reciprocal square root with one Newton step, sum).
+FLOP_ACC_PER_CAM, FLOP_EIGEN, FLOP_ERR_PER_CAM = 66, 220, 36
+FP64_PEAK = 78.6e12                                # MI355X fp64 vector (= matrix) peak, MI355X_MICROARCH.md
+
+
+def fp64_flops_per_step(n_units, C, stats_per_step):
+    level0 = n_units * (C * (FLOP_ACC_PER_CAM + FLOP_ERR_PER_CAM) + FLOP_EIGEN)
+    # a subset evaluation: downdate of the removed cameras (1.2 on average over the levels that occur), eigen-solve,
+    # error over all C cameras (masked)
+    evals = stats_per_step['subsets_evaluated'] * (1.2 * FLOP_ACC_PER_CAM + FLOP_EIGEN + C * FLOP_ERR_PER_CAM)
+    return level0 + evals
 
 
 def main():
@@ -277,6 +330,18 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
     args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    cfg0 = CONFIGS[args.config]
+    cpu = None
+    if not args.no_cpu_baseline and world_env == 1 and not (cfg0.get('assoc') or cfg0.get('single')):
+        # the CPU legs fork worker processes: before anything initialises the GPU in this process
+        import __graft_entry__ as entry0
+        entry0.build_oracle()
+        f1 = args.cpu_frames or {8: 400, 16: 12, 32: 6}.get(cfg0['C'], 100)
+        fall = args.cpu_frames or {8: 2000, 16: 256, 32: 64}.get(cfg0['C'], 500)
+        cpu = cpu_baselines(cfg0, f1, max(fall, f1))
 
     import torch
     import torch.distributed as dist
@@ -322,8 +387,13 @@ def main():
         if multi:
             dist.destroy_process_group()
         return
-    xyl, cams, P, swap, K = make_workload(cfg, rank)
-    F, Pn, C = xyl.shape[0], xyl.shape[1], xyl.shape[2]
+    # ---- triangulation configs -------------------------------------------------------------------------------------------
+    from pose2sim_amd import skeletons, synth, synth_device
+    ids, names, swap_list = skeletons.keypoints(cfg['model'])
+    K, C, Pn, F = len(ids), cfg['C'], cfg['Pn'], cfg['F']
+    swap = np.asarray(swap_list, dtype=np.int32)
+    cams = synth.make_cameras(C, seed=cfg['seed'], distort=cfg['undistort'])
+    P = synth.projection_matrices(cams, cfg['undistort'])
     n_blocks = F * Pn
     n_units = n_blocks * K
 
@@ -333,13 +403,19 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     prm = Engine.tri_params(cfg['thr'], cfg['lik'], cfg['min_cams'], cfg['undistort'], cfg['lr_swap'])
 
-    d_xyl = torch.from_numpy(xyl).to(dev)
+    # Inputs: generated ON THE DEVICE per rank from the seed, in NB distinct buffers that the steps rotate
+    # over, so that no step can be served from the 256 MiB Infinity Cache by the previous one: NB x input >= 1 GiB and
+    # NB >= 4 (one buffer when a single input already exceeds 4 GiB).
+    in_bytes = n_blocks * C * K * 12
+    n_buf = 1 if in_bytes >= (4 << 30) else max(4, -(-(1 << 30) // in_bytes))
+    gen = dict(cfg.get('gen', {}))
+    d_xyls = [synth_device.make_observations_device(cams, F, Pn, K, seed=cfg['seed'] + 977 * rank + 101 * i, device=dev,
+                                                    distort=cfg['undistort'], p_lr_swap=0.02 if cfg['lr_swap'] else 0.0,
+                                                    swap_idx=swap_list, **gen) for i in range(n_buf)]
     d_swap = torch.from_numpy(swap).to(dev)
-    # packed result buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8] -> one all-gather
-    off_e = n_units * 24
-    off_m = off_e + n_units * 4
-    off_n = off_m + n_units * 4
-    nbytes = (off_n + n_units + 15) // 16 * 16
+    # packed result buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8], 16-byte aligned sections -> one all-gather
+    from pose2sim_amd import parallel
+    off_e, off_m, off_n, nbytes = parallel.section_offsets(n_units)
     # two result buffers: the all-gather of step i runs on RCCL's stream while step i+1 computes
     d_outs = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2 if multi else 1)]
     d_alls = [torch.empty(nbytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else []
@@ -350,11 +426,12 @@ def main():
 
     def step():
         i = counter[0] % len(d_outs)
+        x = d_xyls[counter[0] % n_buf]
         counter[0] += 1
         if multi and pending[i] is not None:
             pending[i].wait()                      # buffer i is free again (its all-gather has finished)
         b = d_outs[i].data_ptr()
-        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, b, b + off_e, b + off_n, b + off_m)
+        eng.triangulate_device(n_blocks, K, P2S_F32, x, d_swap, prm, b, b + off_e, b + off_n, b + off_m)
         if multi:
             pending[i] = dist.all_gather_into_tensor(d_alls[i], d_outs[i], async_op=True)
 
@@ -364,8 +441,12 @@ def main():
                 w.wait()
         pending[0] = pending[1] = None
 
+    kcount = [0]
+
     def kernel_only():
-        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, prm, base, base + off_e, base + off_n, base + off_m)
+        x = d_xyls[kcount[0] % n_buf]
+        kcount[0] += 1
+        eng.triangulate_device(n_blocks, K, P2S_F32, x, d_swap, prm, base, base + off_e, base + off_n, base + off_m)
 
     for _ in range(args.warmup):
         step()
@@ -388,7 +469,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline leg: the kernel alone, HIP events on the launch stream
+    # roofline leg: the kernels alone over the same rotation of inputs, HIP events on the launch stream; the
+    # context's counters give the subset evaluations of exactly these steps
+    eng.tri_stats(reset=True)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -397,6 +480,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     k_ms = ev0.elapsed_time(ev1) / args.steps
+    stats = {k: v / args.steps for k, v in eng.tri_stats(reset=True).items()}
 
     # sanity: the timed work produced results
     err = d_out[off_e:off_e + n_units * 4].view(torch.float32)
@@ -405,6 +489,7 @@ def main():
     if rank == 0:
         alg_bytes = n_units * (12 * C + 32)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        flops = fp64_flops_per_step(n_units, C, stats)
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
@@ -412,6 +497,7 @@ def main():
                 traffic = json.load(open(tpath)).get(args.config)
             except Exception:
                 traffic = None
+        fused = (not cfg['undistort']) and (not cfg['lr_swap']) and C <= 16
         out = {
             'metric': 'keypoint-triangulations/sec',
             'value': n_units * world * args.steps / dt,
@@ -422,29 +508,27 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'frames_per_gpu': F, 'cams': C, 'kpts': K, 'persons': Pn,
                        'units_per_gpu': n_units, 'input_dtype': 'f32',
+                       'input_buffers_rotated': n_buf, 'input_bytes_per_buffer': in_bytes, 'generated': 'on device, per rank, from the seed',
                        'params': {'thr_px': cfg['thr'], 'lik_thr': cfg['lik'], 'min_cams': cfg['min_cams'],
                                   'undistort': cfg['undistort'], 'lr_swap': cfg['lr_swap']},
-                       'accepted_fraction': ok_frac, 'tile': eng.tri_geometry(K),
+                       'accepted_fraction': ok_frac,
+                       'search': {'units_entering_search_per_step': stats['search_units'], 'subsets_evaluated_per_step': stats['subsets_evaluated'],
+                                  'capped_units_per_step': stats['capped_units']},
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': ('p2s_tri_level0_direct_kernel' if (C <= 8 or (C <= 16 and not cfg['lr_swap'])) else 'p2s_tri_level0_kernel') + ' + p2s_tri_search_kernel (one pass of the path)', 'kernel_ms': k_ms,
-                         'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
+                         'fp64_frac': flops / (k_ms * 1e-3) / FP64_PEAK, 'fp64_tflops': flops / (k_ms * 1e-3) / 1e12,
+                         'fp64_flop_per_step': flops,
+                         'kernel': ('p2s_tri_fused_kernel (streaming pass + in-wave subset search, one launch)' if fused else
+                                    'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)'),
+                         'kernel_ms': k_ms, 'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }
         if multi:
             # the split a reader needs to judge the scaling: the all-gather moves 33 B per unit into every rank over
             # xGMI (one link per peer), the kernels alone run at kernel_ms per step on every rank
             out['collective'] = {'kind': 'all_gather_into_tensor (RCCL), async, double-buffered', 'bytes_per_rank_per_step': int(nbytes),
                                  'value_kernels_only': n_units * world / (k_ms * 1e-3)}
-        if not args.no_cpu_baseline and world == 1:
-            frames = args.cpu_frames or {8: 400, 16: 12, 32: 8}.get(C, 100)
-            out['cpu_baseline'] = cpu_baseline(cfg, xyl, cams, P, swap, frames)
-            try:                                       # second CPU figure: compiled, all host cores
-                out['cpu_baseline_native'] = cpu_baseline_native(cfg, xyl, cams, P, swap, frames * 250 if C <= 8 else frames * 20)
-            except Exception as e:                     # the C oracle is optional test infrastructure
-                out['cpu_baseline_native'] = {'error': str(e)}
-        else:
-            out['cpu_baseline'] = None
+        out.update(cpu if cpu else {'cpu_baseline': None})
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()

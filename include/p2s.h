@@ -177,19 +177,30 @@ int p2s_butterworth_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_cols, const d
 int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, const double *xyz, int32_t n_bones,
                          const int32_t *bones, double *bone_len, double *bone_stats, double *accel, int64_t *missing);
 
-/* Experiments and tests only -- nothing here changes a result, and the library never reads the environment.
+/* Counters of the triangulation calls of this context since creation (or the last reset), after synchronising its
+ * streams: out[0] units that entered the camera-subset search (triangulation.py:408 beyond the first pass),
+ * out[1] camera subsets evaluated, out[2] 64-lane evaluation passes, out[3] units whose search stopped at the
+ * safety valve (a level with more than 2^26 subsets, i.e. C(32, 11) and beyond, is not entered: such a unit comes
+ * back as not triangulated where the reference would have gone on for hours -- callers report the count). */
+int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
+
+/* Experiments and tests only -- apart from P2S_TUNE_MAX_SUBSETS nothing here changes a result, and the library never
+ * reads the environment.
  *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernel with the in-wave subset search where it
  *                         applies (pinhole, no L/R swap, <= 16 cameras), else the streaming + work-list search pair;
  *                         P2S_TRI_PATH_WORKLIST: always the pair
  *   P2S_TUNE_FORCE_TILED  1: the LDS-tiled streaming kernel even where observations fit in registers
  *   P2S_TUNE_NO_OVERLAP   1: search kernels on the main stream instead of beside the next chunk's streaming pass
  *   P2S_TUNE_SEARCH_JOB   work-list records a search wave takes at a time (8..64; 0 = automatic)
+ *   P2S_TUNE_MAX_SUBSETS  the work-list search does not enter a level with more camera subsets than this (default
+ *                         2^26; this one DOES change results -- tests of the valve only)
  *   P2S_TUNE_DIAG_MODE    kernel diagnostics of a -DP2S_DIAG build (exp/README.md); refused by the shipped library */
 #define P2S_TUNE_TRI_PATH 1
 #define P2S_TUNE_FORCE_TILED 2
 #define P2S_TUNE_NO_OVERLAP 3
 #define P2S_TUNE_SEARCH_JOB 4
 #define P2S_TUNE_DIAG_MODE 5
+#define P2S_TUNE_MAX_SUBSETS 6
 #define P2S_TRI_PATH_AUTO 0
 #define P2S_TRI_PATH_WORKLIST 1
 int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value);

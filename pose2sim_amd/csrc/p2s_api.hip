@@ -73,11 +73,13 @@ struct p2s_ctx {
     hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
     Scratch in, swap, q, err, nexcl, mask, aux0, aux1;
     Scratch wl_rec, wl_count;
+    unsigned long long *d_stats = nullptr;           // P2S_N_STATS counters (p2s_get_tri_stats)
     uint16_t *d_sub_tab = nullptr;                   // camera subsets by level (fused kernel), built with the calibration
     uint32_t *d_sub_off = nullptr;
     // p2s_set_tuning: experiments and tests only, never read from the environment
     int tri_path = P2S_TRI_PATH_AUTO;
     int force_tiled = 0, no_overlap = 0, job = 0;
+    uint32_t max_subsets = P2S_MAX_SUBSETS_PER_LEVEL;
     int debug_mode = 0;                              // honoured by a -DP2S_DIAG build only
 };
 
@@ -203,6 +205,8 @@ int p2s_create(int device_id, p2s_ctx **out) {
     std::vector<uint32_t> b(33 * 33);
     fill_binom(b.data());
     HIP_TRY(hipMemcpy(c->d_binom, b.data(), b.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(unsigned long long) * P2S_N_STATS));
+    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(unsigned long long) * P2S_N_STATS));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -223,6 +227,7 @@ int p2s_destroy(p2s_ctx *ctx) {
     ctx->wl_rec.release(); ctx->wl_count.release();
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->d_binom) (void)hipFree(ctx->d_binom);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_sub_tab) (void)hipFree(ctx->d_sub_tab);
     if (ctx->d_sub_off) (void)hipFree(ctx->d_sub_off);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -315,6 +320,18 @@ int p2s_set_calibration(p2s_ctx *ctx, int32_t n_cams, const double *P, const dou
     return P2S_OK;
 }
 
+int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset) {
+    if (!ctx || !out) return fail(P2S_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    unsigned long long h[P2S_N_STATS];
+    HIP_TRY(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < P2S_N_STATS; ++i) out[i] = h[i];
+    if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, sizeof h));
+    return P2S_OK;
+}
+
 int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
     switch (key) {
@@ -328,6 +345,10 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
     case P2S_TUNE_SEARCH_JOB:
         if (value != 0 && (value < 8 || value > 64)) return fail(P2S_ERR_INVALID_ARG, "search job size %d outside [8, 64]", value);
         ctx->job = value;
+        return P2S_OK;
+    case P2S_TUNE_MAX_SUBSETS:
+        if (value < 1) return fail(P2S_ERR_INVALID_ARG, "max subsets per level must be >= 1");
+        ctx->max_subsets = (uint32_t)value;
         return P2S_OK;
     case P2S_TUNE_DIAG_MODE:
 #ifdef P2S_DIAG
@@ -371,6 +392,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         a.Q = d_Q; a.err = d_err; a.n_excl = d_n_excl; a.mask = d_excl_mask;
         a.cams = ctx->d_cams;
         a.sub_tab = ctx->d_sub_tab; a.sub_off = ctx->d_sub_off;
+        a.stats = ctx->d_stats;
         a.K = n_kpts; a.C = C;
         a.min_cams = params->min_cameras;
         a.thr = params->reproj_error_threshold;
@@ -430,11 +452,13 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     a.Q = d_Q; a.err = d_err; a.n_excl = d_n_excl; a.mask = d_excl_mask;
     a.cams = ctx->d_cams;
     a.binom = ctx->d_binom;
+    a.stats = ctx->d_stats;
     a.K = n_kpts; a.C = C; a.FB = g.FB;
     a.rec_bytes = rec_bytes;
     a.wl_capacity = (uint32_t)shard_cap;
     a.lds_binom_off = lds_binom_off; a.lds_rec_off = lds_rec_off;
     a.job = job;
+    a.max_subsets = ctx->max_subsets;
     a.min_cams = params->min_cameras;
     a.undistort = params->undistort_points ? 1 : 0;
     a.lr_swap = params->handle_lr_swap ? 1 : 0;

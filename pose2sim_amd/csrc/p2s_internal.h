@@ -26,6 +26,11 @@ struct P2sCam {
 #define P2S_DEBUG_MODE(a) 0
 #endif
 
+// p2s_get_tri_stats: [0] units that entered the camera-subset search, [1] camera subsets evaluated (lane-evaluations of
+// DLT + reprojection error beyond level 0), [2] evaluation passes (64-lane), [3] units whose search was cut short by
+// P2S_MAX_SUBSETS_PER_LEVEL (they come back as not triangulated; the reference would have gone on)
+#define P2S_N_STATS 4
+
 #define P2S_MAX_SUBSETS_PER_LEVEL (1u << 26)   // search kernel: deeper levels are not entered (see p2s_tri.hip)
 // The work list is cut into shards (workgroup b appends to shard b % P2S_WL_SHARDS) so that the
 // append counters do not serialise: one returning atomic per wave on ONE word caps near 90 per us.
@@ -41,6 +46,7 @@ struct P2sTriArgs {
     uint32_t *mask;
     const P2sCam *cams;
     const uint32_t *binom;       // [33][33] binomial coefficients
+    unsigned long long *stats;   // [P2S_N_STATS] counters of this context, added to with one atomic per wave (may be NULL)
     const uint16_t *sub_tab;     // fused kernel (C <= 16): every camera subset as a bit mask, by level, in itertools.combinations order
     const uint32_t *sub_off;     // [C + 2] start of level k in sub_tab
     uint32_t *wl_count;          // work list of this chunk: P2S_WL_SHARDS record counts, then P2S_WL_SHARDS job tickets (zeroed before kernel 1)
@@ -52,6 +58,7 @@ struct P2sTriArgs {
     int32_t K, C, FB;
     int32_t lds_binom_off, lds_rec_off;   // kernel 2 LDS layout: [P][binom][records]
     int32_t min_cams, undistort, lr_swap;
+    uint32_t max_subsets;        // search kernel: a level with more subsets is not entered (P2S_MAX_SUBSETS_PER_LEVEL unless tuned)
     int32_t job;                 // work-list records a search wave takes at a time (<= 64); sizes its LDS region
     int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
     double thr, lik_thr;

@@ -436,6 +436,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
     uint64_t t_begin = 0, t_fetch = 0, t_n = 0, t_lvl1 = 0, t_search = 0;
     uint32_t n_jobs = 0;
     if (trace) t_begin = __builtin_amdgcn_s_memrealtime();
+    uint32_t st_units = 0, st_evals = 0, st_passes = 0, st_capped = 0;     // p2s_get_tri_stats (wave-uniform counts)
     for (;;) {
         uint64_t t0 = 0;
         if (trace) t0 = __builtin_amdgcn_s_memtime();
@@ -493,6 +494,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
             if (trace && level == 2) { __builtin_amdgcn_sched_barrier(0); t_lvl1 += __builtin_amdgcn_s_memtime() - t0; }
             unsigned long long pending = pend_level;
             bool cont = false;                                      // owner lanes: continue to level+1
+            bool capped = false;
             const uint32_t nsub = sBinom[C * 33 + level];
             // lanes per unit for this level: the power of two that needs the fewest
             // (passes over the pending units) x (rounds over the level's subsets)
@@ -550,6 +552,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                         go = (pad == low);
                     }
                     if (!__any(go)) continue;
+                    st_evals += (uint32_t)__popcll(__ballot(go)); ++st_passes;
                     const uint32_t Rreal = S & o_valid;
                     const uint32_t kept = o_valid & ~Rreal;
                     const int nkept = __popc(kept);
@@ -631,14 +634,18 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 if (is_owner_now) {
                     err_min = r_err; Qb[0] = r_q0; Qb[1] = r_q1; Qb[2] = r_q2;
                     mask = r_mask; n_excl = r_nexcl;
-                    // safety valve: a level with more than 2^26 subsets (C(32, 10) and beyond) is not entered -- the
-                    // reference would need hours of CPU for that one keypoint; the unit ends as "not triangulated"
-                    cont = (err_min > thr) && (level + 1 <= Lmax) && (P2S_DEBUG_MODE(a) != 3) &&
-                           (sBinom[C * 33 + level + 1] <= P2S_MAX_SUBSETS_PER_LEVEL);
+                    // safety valve: a level with more than 2^26 subsets (C(32, 11) and beyond; C(32, 10) = 64.5 M still
+                    // runs) is not entered -- the reference would need hours of CPU for that one keypoint; the unit
+                    // ends as "not triangulated" and is counted (p2s_get_tri_stats)
+                    const bool more = (err_min > thr) && (level + 1 <= Lmax) && (P2S_DEBUG_MODE(a) != 3);
+                    cont = more && (sBinom[C * 33 + level + 1] <= a.max_subsets);
+                    capped = capped || (more && !cont);
                 }
             }
             pend_level = __ballot(cont);
+            st_capped += (uint32_t)__popcll(__ballot(capped));
         }
+        st_units += (uint32_t)n;
 
         if (trace) { __builtin_amdgcn_sched_barrier(0); t_search += __builtin_amdgcn_s_memtime() - t0; }
         // ---- finalise (triangulation.py:588-604) ------------------------------------------
@@ -655,6 +662,12 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next records overwrite this wave's LDS region
         __builtin_amdgcn_wave_barrier();
+    }
+    if (a.stats && lane == 0 && st_units) {
+        atomicAdd(a.stats + 0, (unsigned long long)st_units);
+        atomicAdd(a.stats + 1, (unsigned long long)st_evals);
+        atomicAdd(a.stats + 2, (unsigned long long)st_passes);
+        if (st_capped) atomicAdd(a.stats + 3, (unsigned long long)st_capped);
     }
     if (trace && lane == 0) {
         double *o = a.Q + (size_t)gwave * 8;

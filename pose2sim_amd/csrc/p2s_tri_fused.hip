@@ -25,7 +25,6 @@ namespace {
 
 constexpr int kSlots = 28;                 // units a wave searches at a time (more: further rounds)
 constexpr uint32_t kNone = 0xffffffffu;
-constexpr int kSubLds = 256;               // subset-table entries kept in LDS
 
 // A searching unit's state in LDS: what the lanes of its group need (normal matrix, masks, the lane that holds its
 // observations in the wave's staging arrays) and the result of the level just finished (written by the winning lane
@@ -75,45 +74,6 @@ __device__ __forceinline__ void load_observations(const P2sTriArgs &a, int C, ui
     }
 }
 
-// Mean reprojection error over the cameras of `kept` (triangulation.py:472-489, common.py:357-403), pinhole model, with
-// the projection matrices read from LDS: as VGPR operands they need none of the v_mov a second SGPR operand of an
-// fp64 FMA costs on gfx950 (one constant-bus read per instruction: 6 moves per camera), and LDS reads return in
-// order, so the next camera's matrix is in flight while this one is used (scalar loads return out of order and each
-// one drains the queue).  Degenerate or NaN operands take camera_distance_exact as in mean_error.
-template <int CT, typename OBS>
-__device__ __forceinline__ double mean_error_lds(const double *sP, cam_cptr cams, int C, const OBS &o, uint32_t kept,
-                                                 const double q[3]) {
-    double sum = 0.0;
-    bool irregular = false;
-    for_each_cam<CT>(C, [&](int c) {
-        double x, y, w;
-        o.raw(c, x, y, w);
-        const double *P = sP + c * 12;
-        const double a = fma(P[0], q[0], fma(P[1], q[1], fma(P[2], q[2], P[3])));
-        const double b = fma(P[4], q[0], fma(P[5], q[1], fma(P[6], q[2], P[7])));
-        const double z = fma(P[8], q[0], fma(P[9], q[1], fma(P[10], q[2], P[11])));
-        const double dxz = fma(-x, z, a), dyz = fma(-y, z, b);
-        const double s = fma(dxz, dxz, dyz * dyz);
-        const double t = s * z * z;
-        const bool reg = (t > 0.0) && (t < kInf);
-        const double d = s * fast_rsqrt(t);
-        const bool k = (kept >> c) & 1u;
-        irregular = irregular || (k && !reg);
-        sum += k ? d : 0.0;
-    });
-    if (__any(irregular)) {                        // rare: some wanted camera is degenerate / NaN
-        double sum2 = 0.0;
-        for_each_cam<CT>(C, [&](int c) {
-            double x, y, w;
-            o.raw(c, x, y, w);
-            const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], x, y);
-            sum2 += ((kept >> c) & 1u) ? d : 0.0;
-        });
-        sum = irregular ? sum2 : sum;
-    }
-    return sum * fast_rcp((double)__popc(kept));   // no camera kept -> NaN, as np.mean([])
-}
-
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -131,8 +91,6 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
     __shared__ __align__(16) unsigned char smem[sizeof(slot_t) * kSlots];
     __shared__ __align__(16) double sP[CT * 12];
     __shared__ uint32_t sList[kSlots];
-    __shared__ uint16_t sSub[kSubLds];         // head of the subset table (all of it up to 8 cameras): a global load per
-                                               // evaluation pass would stall the wave for an L2 round trip
     // results of the wave's 64 units, staged for the 16-byte stores at the end; they are parked here before the search
     // (instead of in 10 registers per lane across it) and the searching units overwrite theirs level by level
     __shared__ __align__(16) double sQ[64 * 3];
@@ -160,14 +118,41 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
     const uint32_t b = u / (uint32_t)K;
     const uint32_t k = u - b * (uint32_t)K;
 
+    // results (triangulation.py:588-604): the three doubles of a unit sit 24 bytes apart; transposing the wave's 64 x 3
+    // block through LDS turns 8-byte-strided stores into 16-byte-per-lane stores of contiguous memory
+    auto store_staged = [&]() {
+        wave_sync();
+        const int64_t gu0 = a.block0 * K + wave_u0;                         // first unit of this wave (global)
+        const int64_t n_left = n_units - wave_u0;                           // units this wave owns
+        double *Qw = a.Q + gu0 * 3;
+        float *Ew = a.err + gu0;
+        uint32_t *Mw = a.mask + gu0;
+        uint8_t *Xw = a.n_excl + gu0;
+        const bool al16 = ((reinterpret_cast<uintptr_t>(Qw) | reinterpret_cast<uintptr_t>(Ew) |
+                            reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(Xw)) & 15) == 0;
+        if (n_left >= 64 && al16) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const v2d *src = reinterpret_cast<const v2d *>(sQ);
+            v2d *dst = reinterpret_cast<v2d *>(Qw);
+            dst[lane] = src[lane];                                          // 1536 contiguous bytes: 64 lanes, then 32
+            if (lane < 32) dst[64 + lane] = src[64 + lane];
+            else if (lane < 48) reinterpret_cast<v4u *>(Ew)[lane - 32] = reinterpret_cast<const v4u *>(sE)[lane - 32];
+            else if (lane < 52) reinterpret_cast<v4u *>(Xw)[lane - 48] = reinterpret_cast<const v4u *>(sX)[lane - 48];
+            if (lane < 16) reinterpret_cast<v4u *>(Mw)[lane] = reinterpret_cast<const v4u *>(sM)[lane];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int idx = r * 64 + lane;
+                if (idx < 3 * n_left) Qw[idx] = sQ[idx];
+            }
+            if (active) { Ew[lane] = __uint_as_float(sE[lane]); Mw[lane] = sM[lane]; Xw[lane] = sX[lane]; }
+        }
+    };
+
     RegObs<T, CT> obs;
     obs.lik_thr = a.lik_thr;
     load_observations<T, CT, EXACT>(a, C, b, k, obs);
-    for (int i = lane; i < C * 12; i += 64) sP[i] = a.cams[i / 12].P[i % 12];
-    {
-        const int n_sub = min(kSubLds, (int)a.sub_off[C + 1]);
-        for (int i = lane; i < n_sub; i += 64) sSub[i] = a.sub_tab[i];
-    }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         sXY[c][lane][0] = obs.x[c]; sXY[c][lane][1] = obs.y[c];
@@ -194,8 +179,7 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
         double q[3];
         smallest_eigvec(N, q);
         if (nvalid < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }   // common.py:347: fewer than 4 rows
-        wave_sync();                                           // sP, and the staged observations for the search
-        const double e = mean_error_lds<CT>(sP, cams, C, obs, valid, q);
+        const double e = mean_error<T, false, CT>(cams, C, obs, valid, q);
         const bool ran = Lmax >= 0;                            // else no level completes: inf, all cameras (:595-596)
         const bool ok = ran && (e <= thr);                     // :600-602
         sQ[lane * 3 + 0] = ok ? q[0] : d_nan();
@@ -210,6 +194,8 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
     // ---- camera-subset search, in this wave ---------------------------------------------------------------------------
     const unsigned long long hard = __ballot(need);
     if (hard != 0ull) {
+        uint32_t st_evals = 0, st_passes = 0;                  // p2s_get_tri_stats (wave-uniform counts)
+        for (int i = lane; i < C * 12; i += 64) sP[i] = a.cams[i / 12].P[i % 12];
         const unsigned long long lt = (1ull << lane) - 1ull;
         const int n_hard = __popcll(hard);
         const int my_ord = __popcll(hard & lt);
@@ -278,7 +264,7 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                         bool go = has && (r < nsub);
                         uint32_t S = 0;
                         if (go) {
-                            S = (sub0 + r < (uint32_t)kSubLds) ? sSub[sub0 + r] : a.sub_tab[sub0 + r];
+                            S = a.sub_tab[sub0 + r];
                             // duplicates of one effective configuration (quirk Q1: a subset that "removes" cameras which
                             // are out already) carry identical numbers; only the lexicographically first one -- its
                             // padding is the LOWEST cameras of the excluded set -- can win the argmin
@@ -287,6 +273,7 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                             go = (o_d & below) == pad;
                         }
                         if (!__any(go)) continue;
+                        st_evals += (uint32_t)__popcll(__ballot(go)); ++st_passes;
                         const uint32_t Rreal = S & o_valid;
                         const uint32_t kept = o_valid & ~Rreal;
                         const int nkept = __popc(kept);
@@ -308,7 +295,7 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                         // them into VGPR lanes and pays a v_readlane per operand)
                         cam_cptr cams_here = cams;
                         asm volatile("" : "+s"(cams_here));
-                        const double e = mean_error_lds<CT>(sP, cams_here, C, sobs, kept, q);
+                        const double e = mean_error<T, false, CT>(cams_here, C, sobs, kept, q);
                         if (go && (e < be || brank == kNone)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
                     }
                     // group argmin, first (lowest-rank) index on ties (np.nanargmin, :502): what the group's first lane
@@ -333,50 +320,25 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
                     const double e = s.err;
                     const uint32_t bS = s.S;
                     const bool ok = e <= thr;
+                    cont = (e > thr) && (level + 1 <= Lmax);
                     sQ[lane * 3 + 0] = ok ? s.q[0] : d_nan();
                     sQ[lane * 3 + 1] = ok ? s.q[1] : d_nan();
                     sQ[lane * 3 + 2] = ok ? s.q[2] : d_nan();
                     sE[lane] = __float_as_uint(ok ? (float)e : __builtin_nanf(""));
                     sM[lane] = nanmask | bS;
                     sX[lane] = (uint8_t)(V + __popc(bS & valid));           // :436 counts NaN or zero
-                    cont = (e > thr) && (level + 1 <= Lmax);
                 }
                 wave_sync();                                                // sList and the result fields are rewritten
             }
         }
-    }
-
-    // ---- results (triangulation.py:588-604): the three doubles of a unit sit 24 bytes apart; transposing the wave's
-    // 64 x 3 block through LDS turns 8-byte-strided stores into 16-byte-per-lane stores of contiguous memory ------------
-    {
-        wave_sync();
-        const int64_t gu0 = a.block0 * K + wave_u0;                         // first unit of this wave (global)
-        const int64_t n_left = n_units - wave_u0;                           // units this wave owns
-        double *Qw = a.Q + gu0 * 3;
-        float *Ew = a.err + gu0;
-        uint32_t *Mw = a.mask + gu0;
-        uint8_t *Xw = a.n_excl + gu0;
-        const bool al16 = ((reinterpret_cast<uintptr_t>(Qw) | reinterpret_cast<uintptr_t>(Ew) |
-                            reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(Xw)) & 15) == 0;
-        if (n_left >= 64 && al16) {
-            typedef double v2d __attribute__((ext_vector_type(2)));
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            const v2d *src = reinterpret_cast<const v2d *>(sQ);
-            v2d *dst = reinterpret_cast<v2d *>(Qw);
-            dst[lane] = src[lane];                                          // 1536 contiguous bytes: 64 lanes, then 32
-            if (lane < 32) dst[64 + lane] = src[64 + lane];
-            else if (lane < 48) reinterpret_cast<v4u *>(Ew)[lane - 32] = reinterpret_cast<const v4u *>(sE)[lane - 32];
-            else if (lane < 52) reinterpret_cast<v4u *>(Xw)[lane - 48] = reinterpret_cast<const v4u *>(sX)[lane - 48];
-            if (lane < 16) reinterpret_cast<v4u *>(Mw)[lane] = reinterpret_cast<const v4u *>(sM)[lane];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int idx = r * 64 + lane;
-                if (idx < 3 * n_left) Qw[idx] = sQ[idx];
-            }
-            if (active) { Ew[lane] = __uint_as_float(sE[lane]); Mw[lane] = sM[lane]; Xw[lane] = sX[lane]; }
+        if (a.stats && lane == 0) {
+            atomicAdd(a.stats + 0, (unsigned long long)n_hard);
+            atomicAdd(a.stats + 1, (unsigned long long)st_evals);
+            atomicAdd(a.stats + 2, (unsigned long long)st_passes);
         }
     }
+
+    store_staged();
 }
 
 template <typename T, int CT>

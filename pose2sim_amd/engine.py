@@ -88,8 +88,15 @@ class Engine:
         _lib.check(self._lib.p2s_synchronize(self._h))
 
     # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
-    TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE = 1, 2, 3, 4, 5
+    TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS = 1, 2, 3, 4, 5, 6
     TRI_PATH_AUTO, TRI_PATH_WORKLIST = 0, 1
+
+    def tri_stats(self, reset=False):
+        """Counters of this engine's triangulation calls: units that entered the camera-subset search, subsets
+        evaluated, 64-lane evaluation passes, units stopped by the 2^26-subsets-per-level safety valve."""
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(self._lib.p2s_get_tri_stats(self._h, _ptr(out), 1 if reset else 0))
+        return {'search_units': int(out[0]), 'subsets_evaluated': int(out[1]), 'passes': int(out[2]), 'capped_units': int(out[3])}
 
     def set_tuning(self, key, value):
         _lib.check(self._lib.p2s_set_tuning(self._h, int(key), int(value)))

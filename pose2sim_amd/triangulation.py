@@ -177,6 +177,11 @@ def triangulate_all(config_dict):
             local = engine.triangulate_packed(xyl, prm, swap_arg, pad_blocks=parallel.largest_shard(n_frames, world) * nb_persons)
         else:
             local = engine.triangulate(xyl, prm, swap_arg)
+        capped = engine.tri_stats(reset=True)['capped_units'] if hasattr(engine, 'tri_stats') else 0
+        if capped:
+            logging.warning(f'{capped} keypoint triangulations were stopped before a camera-subset level of more than 2^26 '
+                            'subsets (the reference would have gone on for hours): they are reported as not triangulated. '
+                            'Raise min_cameras_for_triangulation to bound the search.')
     except Exception as exc:                               # noqa: BLE001 -- re-raised on every rank by agree_ok
         if world == 1:
             raise

@@ -7,7 +7,7 @@ import os
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+R = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', R)
 DST = os.path.join(ROOT, 'profiles', R)
@@ -46,12 +46,14 @@ if stats:
 # instruction mix / issue utilisation per kernel
 names = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY']
 valu = {n: counter_avg('pmc_valu', n)[0] for n in names}
+names2 = ['SQ_WAIT_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_SMEM', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE']
+wait = {n: counter_avg('pmc_wait', n)[0] for n in names2}
 kernels = sorted(k for k in valu['SQ_WAVES'] if k.startswith('p2s_'))
 if kernels:
     with open(os.path.join(DST, 'pmc_valu_cfg2.csv'), 'w') as fh:
-        fh.write('kernel,' + ','.join(names) + ',valu_insts_per_wave,valu_issue_us_at_2.4GHz(insts*4.15cyc/1024 SIMDs)\n')
+        fh.write('kernel,' + ','.join(names + names2) + ',valu_insts_per_wave,valu_issue_us_at_2.4GHz(insts*4.15cyc/1024 SIMDs)\n')
         for k in kernels:
-            vals = [valu[n].get(k, 0.0) for n in names]
+            vals = [valu[n].get(k, 0.0) for n in names] + [wait[n].get(k, 0.0) for n in names2]
             per_wave = vals[1] / max(vals[0], 1.0)
             issue_us = vals[1] * 4.15 / 1024.0 / 2400.0
             fh.write(k + ',' + ','.join('%.0f' % v for v in vals) + ',%.1f,%.1f\n' % (per_wave, issue_us))
@@ -73,11 +75,11 @@ with open(os.path.join(DST, 'pmc_hbm_traffic_cfg2.csv'), 'w') as fh:
         print(r)
 tri = [r for r in rows if r[0].startswith('p2s_tri_')]
 if tri:
-    # cfg2 is one chunk: one launch of each kernel per step
+    # cfg2 is one chunk: one launch of each kernel per step (the one-launch kernel: a single row)
     total = sum(r[6] for r in tri)
     with open(os.path.join(ROOT, 'profiles', 'traffic.json'), 'w') as fh:
         json.dump({'cfg2': total,
-                   '_note': 'HBM bytes per step of bench.py --config cfg2 (both kernels, one launch each per step), rocprofv3 '
+                   '_note': 'HBM bytes per step of bench.py --config cfg2 (every triangulation kernel of a step, inputs rotated over 5 buffers), rocprofv3 '
                             '--pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM '
                             f'section); source: profiles/{R}/pmc_hbm_traffic_cfg2.csv (profiles/collect.sh + summarize.py)'}, fh, indent=1)
     print('traffic per step', total)

@@ -345,3 +345,36 @@ def test_unaligned_device_outputs(engine):
     xd = h[o + 3:o + 3 + n].reshape(F, K)
     assert np.array_equal(Qd, Q.reshape(F, K, 3), equal_nan=True) and np.array_equal(ed, err.reshape(F, K), equal_nan=True)
     assert np.array_equal(md, mask.reshape(F, K)) and np.array_equal(xd, nex.reshape(F, K))
+
+
+def test_search_valve_boundary():
+    """The work-list search does not enter a level with more subsets than the valve (2^26 in production: C(32, 11)
+    and beyond).  With the valve lowered to C(8, 4) = 70 nothing changes; at 69 exactly the units that reach level 4
+    are cut: they come back as not triangulated, are counted, and every other unit is untouched."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from pose2sim_amd import synth
+    from pose2sim_amd.engine import Engine
+    wl = synth.make_config(3000, 8, 26, 1, seed=99, p_outlier=0.30, p_lowlik=0.0, p_missing_cam=0.0)
+    eng = Engine(0)
+    try:
+        eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST)
+        eng.set_calibration(wl['P'])
+        prm = eng.tri_params(4.0, 0.3, 2)
+        ref = eng.triangulate(wl['xyl'], prm)
+        assert eng.tri_stats(reset=True)['capped_units'] == 0
+        eng.set_tuning(Engine.TUNE_MAX_SUBSETS, 70)
+        same = eng.triangulate(wl['xyl'], prm)
+        assert eng.tri_stats(reset=True)['capped_units'] == 0
+        for a, b in zip(ref, same):
+            assert np.array_equal(a, b, equal_nan=True)
+        eng.set_tuning(Engine.TUNE_MAX_SUBSETS, 69)
+        cut = eng.triangulate(wl['xyl'], prm)
+        capped = eng.tri_stats(reset=True)['capped_units']
+        differ = ~(np.isclose(ref[0], cut[0], equal_nan=True, rtol=0, atol=0).all(axis=-1) & (ref[2] == cut[2]) & (ref[3] == cut[3]))
+        assert capped > 0 and differ.sum() == capped
+        assert np.isnan(cut[0][differ]).all() and np.isnan(cut[1][differ]).all()
+        assert (cut[2][differ] == 3).all()                      # nb_cams_excluded of the last level that ran (no camera was out beforehand)
+        assert (ref[2][differ] >= 4).all()                      # the full search went on to level 4 for exactly these units
+    finally:
+        eng.close()
