@@ -18,135 +18,143 @@ from datetime import datetime
 
 import tomli
 
-
-def _toml_load(path):
-    with open(path, 'rb') as f:
-        return tomli.load(f)
-
-
-def setup_logging(session_dir):
-    """Pose2Sim.py:69-75: weekly rotating <session>/logs.txt + stderr, message-only format."""
-    logging.basicConfig(format='%(message)s', level=logging.INFO,
-                        handlers=[logging.handlers.TimedRotatingFileHandler(os.path.join(session_dir, 'logs.txt'), when='D', interval=7),
-                                  logging.StreamHandler()])
+# stage name -> (headline of the log banner, module, function, name used in the "... took" line)
+_STAGES = {
+    'personAssociation': ('Associating persons', 'personAssociation', 'associate_all', 'Associating persons'),
+    'triangulation': ('Triangulation of 2D points', 'triangulation', 'triangulate_all', 'Triangulation'),
+    'filtering': ('Filtering 3D coordinates', 'filtering', 'filter_all', 'Filtering'),
+}
+_OUT_OF_SCOPE = ('calibration', 'poseEstimation', 'synchronization', 'markerAugmentation', 'kinematics', 'runAll')
 
 
-def recursive_update(dict_to_update, dict_with_new_values):
-    """Pose2Sim.py:78-97: deep merge, new values win, untouched keys survive."""
-    for key, value in dict_with_new_values.items():
-        if key in dict_to_update and isinstance(value, dict) and isinstance(dict_to_update[key], dict):
-            dict_to_update[key] = recursive_update(dict_to_update[key], value)
-        else:
-            dict_to_update[key] = value
-    return dict_to_update
+def _load_toml(path):
+    with open(path, 'rb') as fh:
+        return tomli.load(fh)
 
 
-def determine_level(config_dir):
-    """Pose2Sim.py:100-111: 1 = trial folder, 2 = session (root) folder."""
-    len_paths = [len(root.split(os.sep)) for root, dirs, files in os.walk(config_dir) if 'Config.toml' in files]
-    if len_paths == []:
-        raise FileNotFoundError('You need a Config.toml file in each trial or root folder.')
-    return max(len_paths) - min(len_paths) + 1
+def _merged(base, override):
+    """A deep copy of `base` with `override` laid over it: tables merge key by key, anything else is replaced
+    (what the reference's recursive_update does to its first argument, Pose2Sim.py:78-97)."""
+    out = deepcopy(base)
+    stack = [(out, override)]
+    while stack:
+        dst, src = stack.pop()
+        for key, value in src.items():
+            if isinstance(value, dict) and isinstance(dst.get(key), dict):
+                stack.append((dst[key], value))
+            else:
+                dst[key] = value
+    return out
+
+
+def _config_dirs(top):
+    """Directories at or below `top` that hold a Config.toml, in os.walk order, each with its first file name (the
+    reference opens `files[0]` of such a directory, Pose2Sim.py:153) and its depth in path components."""
+    found = []
+    for root, _dirs, files in os.walk(top):
+        if 'Config.toml' in files:
+            found.append((root, files[0], len(root.split(os.sep))))
+    return found
 
 
 def read_config_files(config):
-    """Pose2Sim.py:114-162 -> (level, [config_dict per trial])."""
-    if type(config) == dict:
-        level = 2
-        config_dicts = [config]
-        if config_dicts[0].get('project').get('project_dir') is None:
+    """Pose2Sim.py:100-162 -> (level, [one merged config dict per trial]).
+
+    A dict is taken as it is (level 2).  A directory (None = '.') is a trial when every Config.toml below it sits at one
+    depth (level 1: the parent's Config.toml, if readable, is the session default under the trial's own), else a session
+    (level 2: its Config.toml under each sub-directory's, trials named in exclude_from_batch left out)."""
+    if isinstance(config, dict):
+        if config.get('project').get('project_dir') is None:
             logging.warning('Project directory not specified in config dictionary: using current directory.')
-    else:
-        config_dir = '.' if config is None else config
-        level = determine_level(config_dir)
-        if level == 1:
-            try:
-                session_config_dict = _toml_load(os.path.join(config_dir, '..', 'Config.toml'))
-                trial_config_dict = _toml_load(os.path.join(config_dir, 'Config.toml'))
-                session_config_dict = recursive_update(session_config_dict, trial_config_dict)
-            except Exception:
-                session_config_dict = _toml_load(os.path.join(config_dir, 'Config.toml'))
-            session_config_dict.get('project').update({'project_dir': config_dir})
-            config_dicts = [session_config_dict]
-        if level == 2:
-            session_config_dict = _toml_load(os.path.join(config_dir, 'Config.toml'))
-            config_dicts = []
-            for (root, dirs, files) in os.walk(config_dir):
-                if 'Config.toml' in files and root != config_dir:
-                    trial_config_dict = _toml_load(os.path.join(root, files[0]))
-                    temp_dict = deepcopy(session_config_dict)
-                    temp_dict = recursive_update(temp_dict, trial_config_dict)
-                    temp_dict.get('project').update({'project_dir': os.path.join(config_dir, os.path.relpath(root))})
-                    if not os.path.basename(root) in temp_dict.get('project').get('exclude_from_batch'):
-                        config_dicts.append(temp_dict)
-    return level, config_dicts
-
-
-class Pose2SimPipeline:
-    """Pose2Sim.py:164-248, restricted to the two stages of this engine."""
-
-    def __init__(self, config=None):
-        self.level, self.config_dicts = read_config_files(config)
+        return 2, [config]
+    top = '.' if config is None else config
+    dirs = _config_dirs(top)
+    if not dirs:
+        raise FileNotFoundError('You need a Config.toml file in each trial or root folder.')
+    depths = [d for _, _, d in dirs]
+    level = max(depths) - min(depths) + 1
+    if level == 1:
+        own = os.path.join(top, 'Config.toml')
         try:
-            self.session_dir = os.path.realpath([os.getcwd() if self.level == 2 else os.path.join(os.getcwd(), '..')][0])
-            [os.path.join(self.session_dir, c) for c in os.listdir(self.session_dir)
-             if 'calib' in c.lower() and not c.lower().endswith('.py')][0]
+            cfg = _merged(_load_toml(os.path.join(top, '..', 'Config.toml')), _load_toml(own))
         except Exception:
-            self.session_dir = os.path.realpath(os.getcwd())
-        use_custom_logging = self.config_dicts[0].get('logging', {}).get('use_custom_logging', False)
-        if not use_custom_logging:
-            setup_logging(self.session_dir)
+            cfg = _load_toml(own)
+        cfg.get('project').update({'project_dir': top})
+        return 1, [cfg]
+    session = _load_toml(os.path.join(top, 'Config.toml'))
+    trials = []
+    for root, first_file, _ in dirs:
+        if root == top:
+            continue
+        cfg = _merged(session, _load_toml(os.path.join(root, first_file)))
+        cfg.get('project').update({'project_dir': os.path.join(top, os.path.relpath(root))})
+        if os.path.basename(root) not in cfg.get('project').get('exclude_from_batch'):
+            trials.append(cfg)
+    return level, trials
 
-    def _log_step_header(self, step_name, config_dict):
-        project_dir = os.path.realpath(config_dict.get('project').get('project_dir'))
-        seq_name = os.path.basename(project_dir)
-        frame_range = config_dict.get('project').get('frame_range')
-        frames = 'all frames' if not frame_range or frame_range in ('all', 'auto') else f'frames {frame_range[0]} to {frame_range[1]}'
-        logging.info('\n---------------------------------------------------------------------')
-        logging.info(f'{step_name} for {seq_name}, for {frames}.')
-        logging.info(f"On {datetime.now().strftime('%A %d. %B %Y, %H:%M:%S')}")
-        logging.info(f'Project directory: {project_dir}')
-        logging.info('---------------------------------------------------------------------\n')
 
-    def personAssociation(self):
-        from .personAssociation import associate_all
-        for config_dict in self.config_dicts:
-            self._log_step_header('Associating persons', config_dict)
-            start = time.time()
-            associate_all(config_dict)
-            elapsed = time.time() - start
-            logging.info(f'\nAssociating persons took {time.strftime("%Hh%Mm%Ss", time.gmtime(elapsed))}.\n')
+def _session_dir(level):
+    """Pose2Sim.py:166-171: the working directory (session level) or its parent (trial level) when it holds a
+    calibration folder, else the working directory."""
+    cwd = os.getcwd()
+    candidate = os.path.realpath(cwd if level == 2 else os.path.join(cwd, '..'))
+    try:
+        if any('calib' in c.lower() and not c.lower().endswith('.py') for c in os.listdir(candidate)):
+            return candidate
+    except OSError:
+        pass
+    return os.path.realpath(cwd)
 
-    def triangulation(self):
-        from .triangulation import triangulate_all
-        for config_dict in self.config_dicts:
-            self._log_step_header('Triangulation of 2D points', config_dict)
-            start = time.time()
-            triangulate_all(config_dict)
-            elapsed = time.time() - start
-            logging.info(f'\nTriangulation took {time.strftime("%Hh%Mm%Ss", time.gmtime(elapsed))}.\n')
+
+def _start_logging(session_dir):
+    """Pose2Sim.py:69-75: <session>/logs.txt rotated weekly + the console, message-only lines."""
+    to_file = logging.handlers.TimedRotatingFileHandler(os.path.join(session_dir, 'logs.txt'), when='D', interval=7)
+    logging.basicConfig(format='%(message)s', level=logging.INFO, handlers=[to_file, logging.StreamHandler()])
+
+
+def _banner(headline, config_dict):
+    project_dir = os.path.realpath(config_dict.get('project').get('project_dir'))
+    frame_range = config_dict.get('project').get('frame_range')
+    which = 'all frames' if not frame_range or frame_range in ('all', 'auto') else f'frames {frame_range[0]} to {frame_range[1]}'
+    rule = '---------------------------------------------------------------------'
+    for line in ('\n' + rule, f'{headline} for {os.path.basename(project_dir)}, for {which}.',
+                 f"On {datetime.now().strftime('%A %d. %B %Y, %H:%M:%S')}", f'Project directory: {project_dir}', rule + '\n'):
+        logging.info(line)
+
+
+def _run_stage(name, config):
+    headline, module, function, done = _STAGES[name]
+    level, config_dicts = read_config_files(config)
+    if not config_dicts[0].get('logging', {}).get('use_custom_logging', False):
+        _start_logging(_session_dir(level))
+    run = getattr(__import__(f'{__package__}.{module}', fromlist=[function]), function)
+    for config_dict in config_dicts:
+        _banner(headline, config_dict)
+        start = time.time()
+        run(config_dict)
+        logging.info(f'\n{done} took {time.strftime("%Hh%Mm%Ss", time.gmtime(time.time() - start))}.\n')
 
 
 def personAssociation(config=None):
-    Pose2SimPipeline(config).personAssociation()
+    _run_stage('personAssociation', config)
 
 
 def triangulation(config=None):
-    Pose2SimPipeline(config).triangulation()
+    _run_stage('triangulation', config)
 
 
-def _not_covered(name):
+def filtering(config=None):
+    """Butterworth filtering of the .trc files (the other filter types are refused by filtering.filter_all)."""
+    _run_stage('filtering', config)
+
+
+def _out_of_scope(name):
     def stage(config=None):
-        raise NotImplementedError(f'Pose2Sim.{name}() is outside the scope of this engine (it covers '
-                                  'personAssociation and triangulation); run that stage with the reference.')
+        raise NotImplementedError(f'Pose2Sim.{name}() is outside the scope of this engine (it covers personAssociation, '
+                                  'triangulation and Butterworth filtering); run that stage with the reference.')
     stage.__name__ = name
     return stage
 
 
-calibration = _not_covered('calibration')
-poseEstimation = _not_covered('poseEstimation')
-synchronization = _not_covered('synchronization')
-filtering = _not_covered('filtering')
-markerAugmentation = _not_covered('markerAugmentation')
-kinematics = _not_covered('kinematics')
-runAll = _not_covered('runAll')
+for _name in _OUT_OF_SCOPE:
+    globals()[_name] = _out_of_scope(_name)

@@ -205,8 +205,8 @@ int p2s_create(int device_id, p2s_ctx **out) {
     std::vector<uint32_t> b(33 * 33);
     fill_binom(b.data());
     HIP_TRY(hipMemcpy(c->d_binom, b.data(), b.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(unsigned long long) * P2S_N_STATS));
-    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(unsigned long long) * P2S_N_STATS));
+    HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(unsigned long long) * P2S_STAT_SHARDS * P2S_STAT_STRIDE));
+    HIP_TRY(hipMemset(c->d_stats, 0, sizeof(unsigned long long) * P2S_STAT_SHARDS * P2S_STAT_STRIDE));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -325,10 +325,13 @@ int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
-    unsigned long long h[P2S_N_STATS];
-    HIP_TRY(hipMemcpy(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost));
-    for (int i = 0; i < P2S_N_STATS; ++i) out[i] = h[i];
-    if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, sizeof h));
+    std::vector<unsigned long long> h((size_t)P2S_STAT_SHARDS * P2S_STAT_STRIDE);
+    HIP_TRY(hipMemcpy(h.data(), ctx->d_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < P2S_N_STATS; ++i) {
+        out[i] = 0;
+        for (int sh = 0; sh < P2S_STAT_SHARDS; ++sh) out[i] += h[(size_t)sh * P2S_STAT_STRIDE + i];
+    }
+    if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, h.size() * sizeof(unsigned long long)));
     return P2S_OK;
 }
 

@@ -30,6 +30,10 @@ struct P2sCam {
 // DLT + reprojection error beyond level 0), [2] evaluation passes (64-lane), [3] units whose search was cut short by
 // P2S_MAX_SUBSETS_PER_LEVEL (they come back as not triangulated; the reference would have gone on)
 #define P2S_N_STATS 4
+// the counters are kept in shards of their own 64-byte lines (a wave adds to shard blockIdx % P2S_STAT_SHARDS): one
+// word takes ~88 atomics per microsecond, and 40 000 waves adding to ONE word cost 1.2 ms per launch
+#define P2S_STAT_SHARDS 256
+#define P2S_STAT_STRIDE 8        // unsigned long long per shard (64 bytes)
 
 #define P2S_MAX_SUBSETS_PER_LEVEL (1u << 26)   // search kernel: deeper levels are not entered (see p2s_tri.hip)
 // The work list is cut into shards (workgroup b appends to shard b % P2S_WL_SHARDS) so that the

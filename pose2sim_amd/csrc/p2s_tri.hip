@@ -664,10 +664,11 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         __builtin_amdgcn_wave_barrier();
     }
     if (a.stats && lane == 0 && st_units) {
-        atomicAdd(a.stats + 0, (unsigned long long)st_units);
-        atomicAdd(a.stats + 1, (unsigned long long)st_evals);
-        atomicAdd(a.stats + 2, (unsigned long long)st_passes);
-        if (st_capped) atomicAdd(a.stats + 3, (unsigned long long)st_capped);
+        unsigned long long *st = a.stats + (size_t)(blockIdx.x % P2S_STAT_SHARDS) * P2S_STAT_STRIDE;
+        atomicAdd(st + 0, (unsigned long long)st_units);
+        atomicAdd(st + 1, (unsigned long long)st_evals);
+        atomicAdd(st + 2, (unsigned long long)st_passes);
+        if (st_capped) atomicAdd(st + 3, (unsigned long long)st_capped);
     }
     if (trace && lane == 0) {
         double *o = a.Q + (size_t)gwave * 8;

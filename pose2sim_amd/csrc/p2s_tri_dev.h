@@ -384,17 +384,11 @@ __device__ __forceinline__ double camera_distance(cam_cptr cam, const double q[3
         regular = true;
         return pair_distance(u - x, v - y);
     }
-#ifdef P2S_V_MULFIRST
     // an fp64 FMA reads one SGPR: with the constant term as the addend of the innermost FMA the compiler first moves it
-    // to a VGPR pair (2 v_mov per row); multiply first and add the constant last instead (one instruction fewer per row)
+    // to a VGPR pair (2 v_mov per row); multiplying first and adding the constant last is one instruction fewer per row
     const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], cam->P[2] * q[2])) + cam->P[3];
     const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], cam->P[6] * q[2])) + cam->P[7];
     const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], cam->P[10] * q[2])) + cam->P[11];
-#else
-    const double a = fma(cam->P[0], q[0], fma(cam->P[1], q[1], fma(cam->P[2], q[2], cam->P[3])));
-    const double b = fma(cam->P[4], q[0], fma(cam->P[5], q[1], fma(cam->P[6], q[2], cam->P[7])));
-    const double z = fma(cam->P[8], q[0], fma(cam->P[9], q[1], fma(cam->P[10], q[2], cam->P[11])));
-#endif
     const double dxz = fma(-x, z, a), dyz = fma(-y, z, b);
     const double s = fma(dxz, dxz, dyz * dyz);
     const double t = s * z * z;

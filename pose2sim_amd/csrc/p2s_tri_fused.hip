@@ -332,9 +332,10 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
             }
         }
         if (a.stats && lane == 0) {
-            atomicAdd(a.stats + 0, (unsigned long long)n_hard);
-            atomicAdd(a.stats + 1, (unsigned long long)st_evals);
-            atomicAdd(a.stats + 2, (unsigned long long)st_passes);
+            unsigned long long *st = a.stats + (size_t)(blockIdx.x % P2S_STAT_SHARDS) * P2S_STAT_STRIDE;
+            atomicAdd(st + 0, (unsigned long long)n_hard);
+            atomicAdd(st + 1, (unsigned long long)st_evals);
+            atomicAdd(st + 2, (unsigned long long)st_passes);
         }
     }
 

@@ -132,32 +132,39 @@ def rewrite_json_files_batch(dst_files, src_files, proposals_per_frame, n_cams):
     _lib.check(lib.p2s_json_rewrite_people(sblob, ptr(soff), dblob, ptr(doff), n, ptr(sel_off), ptr(sel), 0, None))
 
 
+_RECAP = {
+    'single': ('\n--> Mean reprojection error for {kpt} point on all frames is {px} px, which roughly corresponds to {mm} mm. ',
+               '--> In average, {cams} cameras had to be excluded to reach the demanded {thr} px error threshold after excluding points with likelihood below {lik}.'),
+    'multi': ('\n--> A person was reconstructed if the lines from cameras to their keypoints intersected within {recon} m and if the calculated affinity stayed above {aff}.',
+              '--> Beware that people were sorted across cameras, but not across frames. This will be done in the triangulation stage.'),
+    'stored': '\nTracked json files are stored in {path}.',
+}
+
+
 def recap_tracking(config_dict, error=0, nb_cams_excluded=0):
-    """personAssociation.py:583-639."""
+    """The report of personAssociation.py:583-639: single-person mode -- mean reprojection error of the tracked keypoint
+    (px, and mm through the first camera's focal length and distance) and mean number of cameras switched off;
+    multi-person mode -- the two thresholds in force; then where the files went."""
     project_dir = config_dict.get('project').get('project_dir')
-    session_dir = os.path.realpath(os.path.join(project_dir, '..'))
-    session_dir = session_dir if 'Config.toml' in os.listdir(session_dir) else os.getcwd()
-    multi_person = config_dict.get('project').get('multi_person')
-    likelihood_threshold_association = config_dict.get('personAssociation').get('single_person').get('likelihood_threshold_association', 0.3)
-    tracked_keypoint = config_dict.get('personAssociation').get('single_person').get('tracked_keypoint')
-    error_threshold_tracking = config_dict.get('personAssociation').get('single_person').get('reproj_error_threshold_association')
-    reconstruction_error_threshold = config_dict.get('personAssociation').get('multi_person').get('reconstruction_error_threshold')
-    min_affinity = config_dict.get('personAssociation').get('multi_person').get('min_affinity')
-    poseTracked_dir = os.path.join(project_dir, 'pose-associated')
-    if not multi_person:
-        calib = calib_mod.load_toml(calib_mod.find_calibration_file(session_dir))
-        calib_cam1 = calib[calib_mod.camera_keys(calib)[0]]
-        fm = calib_cam1['matrix'][0][0]
-        Dm = float(np.sqrt(np.sum(np.array(calib_cam1['translation'], dtype=np.float64) ** 2)))
-        mean_error_px = np.around(np.nanmean(error), decimals=1)
-        mean_error_mm = np.around(mean_error_px * Dm / fm * 1000, decimals=1)
-        mean_cam_off_count = np.around(np.mean(nb_cams_excluded), decimals=2)
-        logging.info(f'\n--> Mean reprojection error for {tracked_keypoint} point on all frames is {mean_error_px} px, which roughly corresponds to {mean_error_mm} mm. ')
-        logging.info(f'--> In average, {mean_cam_off_count} cameras had to be excluded to reach the demanded {error_threshold_tracking} px error threshold after excluding points with likelihood below {likelihood_threshold_association}.')
+    pcfg = config_dict.get('personAssociation')
+    if config_dict.get('project').get('multi_person'):
+        values = dict(recon=pcfg.get('multi_person').get('reconstruction_error_threshold'), aff=pcfg.get('multi_person').get('min_affinity'))
+        lines = _RECAP['multi']
     else:
-        logging.info(f'\n--> A person was reconstructed if the lines from cameras to their keypoints intersected within {reconstruction_error_threshold} m and if the calculated affinity stayed above {min_affinity}.')
-        logging.info('--> Beware that people were sorted across cameras, but not across frames. This will be done in the triangulation stage.')
-    logging.info(f'\nTracked json files are stored in {os.path.realpath(poseTracked_dir)}.')
+        session_dir = os.path.realpath(os.path.join(project_dir, '..'))
+        session_dir = session_dir if 'Config.toml' in os.listdir(session_dir) else os.getcwd()
+        calib = calib_mod.load_toml(calib_mod.find_calibration_file(session_dir))
+        first_cam = calib[calib_mod.camera_keys(calib)[0]]
+        px_to_mm = float(np.sqrt(np.sum(np.array(first_cam['translation'], dtype=np.float64) ** 2))) / first_cam['matrix'][0][0] * 1000
+        px = np.around(np.nanmean(error), decimals=1)
+        single = pcfg.get('single_person')
+        values = dict(kpt=single.get('tracked_keypoint'), px=px, mm=np.around(px * px_to_mm, decimals=1),
+                      cams=np.around(np.mean(nb_cams_excluded), decimals=2), thr=single.get('reproj_error_threshold_association'),
+                      lik=single.get('likelihood_threshold_association', 0.3))
+        lines = _RECAP['single']
+    for line in lines:
+        logging.info(line.format(**values))
+    logging.info(_RECAP['stored'].format(path=os.path.realpath(os.path.join(project_dir, 'pose-associated'))))
 
 
 def single_person_candidates(paths, k3):

@@ -262,81 +262,99 @@ def triangulate_all(config_dict):
     return trc_paths
 
 
+# ---- the stage's report (triangulation.py:255-360): message templates as data, one pass over a table of values -------
+_MSG = {
+    'participant': '\n\nPARTICIPANT {n}\n',
+    'keypoint': 'Mean reprojection error for {name} is {px} px (~ {m} m), reached with {cams} excluded cameras. ',
+    'none_needed': '  No frames needed to be interpolated.',
+    'interpolated': '  Frames {spans} were interpolated.',
+    'not_interpolated': '  Frames {spans} were not interpolated.',
+    'interp_off': "  No frames were interpolated because 'interpolation_kind' was set to none. ",
+    'overall': '\n--> Mean reprojection error for all points on frames {first} to {last} is {px} px, which roughly corresponds to {mm} mm. ',
+    'thresholds': 'Cameras were excluded if likelihood was below {lik} and if the reprojection error was above {thr} px.',
+    'gaps': 'Gaps were interpolated with {kind} method if smaller than {gap} frames. Larger gaps were filled with {filler}.',
+    'excluded': 'In average, {cams} cameras had to be excluded to reach these thresholds.',
+    'trimmed': '\nSome frames could not be correctly triangulated: trial trimmed between frames {span}.\n'
+               'You might need to tweak the triangulation parameters in Config.toml (for example, try increasing "reproj_error_threshold_triangulation").',
+    'stored': '3D coordinates are stored at {path}.',
+    'c3d': 'All trc files have been converted to c3d.',
+    'swap': 'Limb swapping was {state}.',
+    'distortion': 'Lens distortions were {state}.',
+}
+_FILLERS = {'last_value': 'the last valid value', 'zeros': 'zeros'}
+
+
+def _spans(ranges):
+    """['3:7', '12:12'] -> '3 to 7, 12 to 12' (the reference prints the list and strips its punctuation)."""
+    return ', '.join(r.replace(':', ' to ') for r in ranges)
+
+
+def _camera_sentence(fractions):
+    """'Camera A was excluded 13% of the time, Camera B: 12%, and Camera C: 9%.' -- cameras by falling share."""
+    ranked = sorted(fractions.items(), key=lambda kv: kv[1])[::-1]
+    parts = []
+    for i, (cam, frac) in enumerate(ranked):
+        pct = int(np.round(frac * 100))
+        if i == 0:
+            parts.append(f'Camera {cam} was excluded {pct}% of the time, ')
+        elif i == len(ranked) - 1:
+            parts.append(f'and Camera {cam}: {pct}%.')
+        else:
+            parts.append(f'Camera {cam}: {pct}%, ')
+    return ''.join(parts)
+
+
 def recap_triangulate(config_dict, error, nb_cams_excluded, keypoints_names, cam_excluded_count, interp_frames,
                       non_interp_frames, f_range_trimmed, f_range, trc_paths, calib_file):
-    """Log lines of triangulation.py:255-360."""
+    """The report of triangulation.py:255-360: per keypoint the mean reprojection error (px, and metres through the first
+    camera's focal length and distance) and mean number of excluded cameras, the interpolated frame spans, the
+    trial-wide means, the thresholds in force, each camera's share of exclusions, where the file went."""
+    tcfg = config_dict.get('triangulation')
     calib = calib_mod.load_toml(calib_file)
     cal_keys = calib_mod.camera_keys(calib)
-    cam_names = np.array([calib[c].get('name') if calib[c].get('name') else c for c in cal_keys])
-    tcfg = config_dict.get('triangulation')
-    error_threshold_triangulation = tcfg.get('reproj_error_threshold_triangulation')
-    likelihood_threshold = tcfg.get('likelihood_threshold_triangulation')
-    min_chunk_size = tcfg.get('min_chunk_size', 10)
-    show_interp_indices = tcfg.get('show_interp_indices')
-    interpolation_kind = tcfg.get('interpolation')
-    interp_gap_smaller_than = tcfg.get('interp_if_gap_smaller_than')
-    fill_large_gaps_with = tcfg.get('fill_large_gaps_with')
-    make_c3d = tcfg.get('make_c3d')
-    handle_LR_swap = tcfg.get('handle_LR_swap')
-    undistort_points = tcfg.get('undistort_points')
+    cam_names = [calib[c].get('name') if calib[c].get('name') else c for c in cal_keys]
+    first_cam = calib[cal_keys[0]]
+    px_to_m = float(np.sqrt(np.sum(np.array(first_cam['translation'], dtype=np.float64) ** 2))) / first_cam['matrix'][0][0]
+    kind = tcfg.get('interpolation')
+    min_chunk = tcfg.get('min_chunk_size', 10)
+    say = logging.info
 
-    calib_cam1 = calib[cal_keys[0]]
-    fm = calib_cam1['matrix'][0][0]
-    Dm = float(np.sqrt(np.sum(np.array(calib_cam1['translation'], dtype=np.float64) ** 2)))
-
-    logging.info('')
-    nb_persons = len(error)
-    for n in range(nb_persons):
+    say('')
+    persons = [n for n in range(len(error)) if f_range_trimmed[n][1] - f_range_trimmed[n][0] > min_chunk]
+    for n in persons:
         first, last = f_range_trimmed[n]
-        if last - first <= min_chunk_size:
-            continue
-        if nb_persons > 1:
-            logging.info(f'\n\nPARTICIPANT {n}\n')
+        if len(error) > 1:
+            say(_MSG['participant'].format(n=n))
         for idx, name in enumerate(keypoints_names):
-            mean_error_keypoint_px = np.around(error[n].iloc[:, idx].mean(), decimals=1)
-            mean_error_keypoint_m = np.around(mean_error_keypoint_px * Dm / fm, decimals=3)
-            mean_cam_excluded_keypoint = np.around(nb_cams_excluded[n].iloc[:, idx].mean(), decimals=2)
-            logging.info(f'Mean reprojection error for {name} is {mean_error_keypoint_px} px (~ {mean_error_keypoint_m} m), reached with {mean_cam_excluded_keypoint} excluded cameras. ')
-            if show_interp_indices:
-                if interpolation_kind != 'none':
-                    if len(list(interp_frames[n][idx])) == 0 and len(list(non_interp_frames[n][idx])) == 0:
-                        logging.info('  No frames needed to be interpolated.')
-                    if len(list(interp_frames[n][idx])) > 0:
-                        s = str(interp_frames[n][idx]).replace(':', ' to ').replace("'", '').replace(']', '').replace('[', '')
-                        logging.info(f'  Frames {s} were interpolated.')
-                    if len(list(non_interp_frames[n][idx])) > 0:
-                        s = str(non_interp_frames[n][idx]).replace(':', ' to ').replace("'", '').replace(']', '').replace('[', '')
-                        logging.info(f'  Frames {s} were not interpolated.')
-                else:
-                    logging.info("  No frames were interpolated because 'interpolation_kind' was set to none. ")
-
-        mean_error_px = np.around(error[n]['mean'].mean(), decimals=1)
-        mean_error_mm = np.around(mean_error_px * Dm / fm * 1000, decimals=1)
-        mean_cam_excluded = np.around(nb_cams_excluded[n]['mean'].mean(), decimals=2)
-        logging.info(f'\n--> Mean reprojection error for all points on frames {first} to {last} is {mean_error_px} px, which roughly corresponds to {mean_error_mm} mm. ')
-        logging.info(f'Cameras were excluded if likelihood was below {likelihood_threshold} and if the reprojection error was above {error_threshold_triangulation} px.')
-        if interpolation_kind != 'none':
-            filler = 'the last valid value' if fill_large_gaps_with == 'last_value' else 'zeros' if fill_large_gaps_with == 'zeros' else 'NaNs'
-            logging.info(f'Gaps were interpolated with {interpolation_kind} method if smaller than {interp_gap_smaller_than} frames. Larger gaps were filled with {filler}.')
-        logging.info(f'In average, {mean_cam_excluded} cameras had to be excluded to reach these thresholds.')
+            px = np.around(error[n].iloc[:, idx].mean(), decimals=1)
+            say(_MSG['keypoint'].format(name=name, px=px, m=np.around(px * px_to_m, decimals=3),
+                                        cams=np.around(nb_cams_excluded[n].iloc[:, idx].mean(), decimals=2)))
+            if not tcfg.get('show_interp_indices'):
+                continue
+            if kind == 'none':
+                say(_MSG['interp_off'])
+                continue
+            done, left = list(interp_frames[n][idx]), list(non_interp_frames[n][idx])
+            if not done and not left:
+                say(_MSG['none_needed'])
+            if done:
+                say(_MSG['interpolated'].format(spans=_spans(done)))
+            if left:
+                say(_MSG['not_interpolated'].format(spans=_spans(left)))
+        px = np.around(error[n]['mean'].mean(), decimals=1)
+        say(_MSG['overall'].format(first=first, last=last, px=px, mm=np.around(px * px_to_m * 1000, decimals=1)))
+        say(_MSG['thresholds'].format(lik=tcfg.get('likelihood_threshold_triangulation'), thr=tcfg.get('reproj_error_threshold_triangulation')))
+        if kind != 'none':
+            say(_MSG['gaps'].format(kind=kind, gap=tcfg.get('interp_if_gap_smaller_than'),
+                                    filler=_FILLERS.get(tcfg.get('fill_large_gaps_with'), 'NaNs')))
+        say(_MSG['excluded'].format(cams=np.around(nb_cams_excluded[n]['mean'].mean(), decimals=2)))
         if len(range(first, last)) < len(range(*f_range)):
-            logging.warning(f'\nSome frames could not be correctly triangulated: trial trimmed between frames {f_range_trimmed[n]}.\n' +
-                            'You might need to tweak the triangulation parameters in Config.toml (for example, try increasing "reproj_error_threshold_triangulation").')
-        named = {cam_names[i]: v for i, v in cam_excluded_count[n].items()}
-        named = {k: v for k, v in sorted(named.items(), key=lambda item: item[1])[::-1]}
-        msg = ''
-        for i, (k, v) in enumerate(named.items()):
-            if i == 0:
-                msg += f'Camera {k} was excluded {int(np.round(v * 100))}% of the time, '
-            elif i == len(named) - 1:
-                msg += f'and Camera {k}: {int(np.round(v * 100))}%.'
-            else:
-                msg += f'Camera {k}: {int(np.round(v * 100))}%, '
-        logging.info(msg)
-        logging.info(f'3D coordinates are stored at {trc_paths[n]}.')
+            logging.warning(_MSG['trimmed'].format(span=f_range_trimmed[n]))
+        say(_camera_sentence({cam_names[i]: v for i, v in cam_excluded_count[n].items()}))
+        say(_MSG['stored'].format(path=trc_paths[n]))
 
-    logging.info('\n\n')
-    if make_c3d:
-        logging.info('All trc files have been converted to c3d.')
-    logging.info(f'Limb swapping was {"handled" if handle_LR_swap else "not handled"}.')
-    logging.info(f'Lens distortions were {"taken into account" if undistort_points else "not taken into account"}.')
+    say('\n\n')
+    if tcfg.get('make_c3d'):
+        say(_MSG['c3d'])
+    say(_MSG['swap'].format(state='handled' if tcfg.get('handle_LR_swap') else 'not handled'))
+    say(_MSG['distortion'].format(state='taken into account' if tcfg.get('undistort_points') else 'not taken into account'))

@@ -87,4 +87,4 @@ def test_batch_session_runs_every_trial_but_the_excluded_one(tmp_path, monkeypat
     Pose2Sim.triangulation()
     assert open(os.path.join(root, 'Trial_2', 'pose-3d', out2[0])).read() == first
     with pytest.raises(NotImplementedError):
-        Pose2Sim.filtering(root)
+        Pose2Sim.kinematics(root)
