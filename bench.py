@@ -277,7 +277,7 @@ def cpu_baselines(cfg, frames_1core, frames_all):
     dt = time.perf_counter() - t0
     out['cpu_baseline_1core'] = {'value': frames_1core * per_frame / dt, 'unit': 'keypoint-triangulations/s', 'cores': 1, 'kind': 'port',
                                  'sample': f'first {frames_1core} frames of the same workload ({frames_1core * per_frame} units, {dt:.1f} s), NumPy oracle, arithmetic only'}
-    workers = max(1, min(cores, frames_all))
+    workers = max(1, min(cores, frames_all, 64))              # 64 processes: beyond that the fork / pickle overhead of a ~10 s sample dominates
     bounds = np.linspace(0, frames_all, workers + 1).astype(int)
     jobs = [(xyl[a:b], P, cams, swap, cfg['lik'], cfg['thr'], cfg['min_cams'], cfg['lr_swap'], cfg['undistort'])
             for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
@@ -339,8 +339,10 @@ def main():
         # the CPU legs fork worker processes: before anything initialises the GPU in this process
         import __graft_entry__ as entry0
         entry0.build_oracle()
+        # ~2.5 s of single-core work per process: 400 frames at 8 cameras (4.3e3 units/s/core), fewer where a unit is dearer
         f1 = args.cpu_frames or {8: 400, 16: 12, 32: 6}.get(cfg0['C'], 100)
-        fall = args.cpu_frames or {8: 2000, 16: 256, 32: 64}.get(cfg0['C'], 500)
+        n_cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        fall = args.cpu_frames or max(2000 if cfg0['C'] <= 8 else 0, f1 * min(n_cores, 64))
         cpu = cpu_baselines(cfg0, f1, max(fall, f1))
 
     import torch

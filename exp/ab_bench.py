@@ -38,6 +38,7 @@ def main():
     Pm = np.ascontiguousarray(np.asarray(P, dtype=np.float64).reshape(-1, 12))
     stream = torch.cuda.current_stream().cuda_stream
     variants = []
+    keep = []
     for spec in args.libs:
         name, path = spec.split('=', 1)
         lib = C.CDLL(os.path.abspath(path))
@@ -47,7 +48,15 @@ def main():
                 getattr(lib, fn).argtypes = argt
         h = C.c_void_p()
         assert lib.p2s_create(0, C.byref(h)) == 0
-        assert lib.p2s_set_calibration(h, Pm.shape[0], Pm.ctypes.data_as(C.c_void_p), None, None, None, None, None) == 0
+        n = Pm.shape[0]
+        Kc = np.ascontiguousarray(np.asarray(cams['K'], dtype=np.float64).reshape(n, 9))
+        dc = np.zeros((n, 5)); dc[:, :4] = np.asarray(cams['dist'], dtype=np.float64).reshape(n, -1)[:, :4]
+        Rc = np.ascontiguousarray(np.asarray(cams['R_mat'], dtype=np.float64).reshape(n, 9))
+        Tc = np.ascontiguousarray(np.asarray(cams['T'], dtype=np.float64).reshape(n, 3))
+        nk = np.ascontiguousarray(np.asarray(cams['optim_K'], dtype=np.float64).reshape(n, 9))
+        keep.append((Kc, dc, Rc, Tc, nk))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)                      # noqa: E731
+        assert lib.p2s_set_calibration(h, n, ptr(Pm), ptr(Kc), ptr(dc), ptr(Rc), ptr(Tc), ptr(nk)) == 0
         assert lib.p2s_set_stream(h, C.c_void_p(stream)) == 0
 
         def run(lib=lib, h=h):
