@@ -12,7 +12,10 @@
  *     last failure.
  *   - one context per GPU per process; a context is not re-entrant.
  *   - "_device" entry points take DEVICE pointers and enqueue on the context's stream without
- *     synchronising; "_host" entry points take HOST pointers, copy in/out and block.
+ *     synchronising; "_host" entry points take HOST pointers, copy in/out and block.  One exception:
+ *     p2s_triangulate_device with more than 16 cameras (or undistortion / L/R swap and a camera count whose subset
+ *     levels can exceed 16 384 subsets) reads a 4-byte count after each chunk's search to drive the deep-level
+ *     rounds, i.e. it synchronises the stream.
  *   - observation tensor layout: xyl[n_blocks][C][K][3] (x px, y px, likelihood), one block
  *     per (frame, person); NaN = missing.  dtype float32 or float64 (P2S_F32 / P2S_F64).
  *   - camera count C <= P2S_MAX_CAMS (the excluded-camera set is returned as a 32-bit mask).
@@ -194,6 +197,8 @@ int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
  *   P2S_TUNE_SEARCH_JOB   work-list records a search wave takes at a time (8..64; 0 = automatic)
  *   P2S_TUNE_MAX_SUBSETS  the work-list search does not enter a level with more camera subsets than this (default
  *                         2^26; this one DOES change results -- tests of the valve only)
+ *   P2S_TUNE_DEEP_MIN_SUBSETS  levels of the work-list search with more camera subsets than this (default 16 384) are
+ *                         cut into chunks and spread over the whole GPU instead of being walked by one wave; 0 = never
  *   P2S_TUNE_DIAG_MODE    kernel diagnostics of a -DP2S_DIAG build (exp/README.md); refused by the shipped library */
 #define P2S_TUNE_TRI_PATH 1
 #define P2S_TUNE_FORCE_TILED 2
@@ -201,6 +206,7 @@ int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 #define P2S_TUNE_SEARCH_JOB 4
 #define P2S_TUNE_DIAG_MODE 5
 #define P2S_TUNE_MAX_SUBSETS 6
+#define P2S_TUNE_DEEP_MIN_SUBSETS 7
 #define P2S_TRI_PATH_AUTO 0
 #define P2S_TRI_PATH_WORKLIST 1
 int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value);

@@ -73,6 +73,8 @@ struct p2s_ctx {
     hipEvent_t ev_k1[2] = {nullptr, nullptr}, ev_k2[2] = {nullptr, nullptr};
     Scratch in, swap, q, err, nexcl, mask, aux0, aux1;
     Scratch wl_rec, wl_count;
+    Scratch deep_entries, deep_ctl, deep_sched, deep_partials;   // deep levels of the search (p2s_tri_deep.hip)
+    uint32_t deep_min_subsets = P2S_DEEP_MIN_SUBSETS;            // 0 = every level stays in the search kernel's wave
     unsigned long long *d_stats = nullptr;           // P2S_N_STATS counters (p2s_get_tri_stats)
     uint16_t *d_sub_tab = nullptr;                   // camera subsets by level (fused kernel), built with the calibration
     uint32_t *d_sub_off = nullptr;
@@ -225,6 +227,7 @@ int p2s_destroy(p2s_ctx *ctx) {
     ctx->in.release(); ctx->swap.release(); ctx->q.release(); ctx->err.release();
     ctx->nexcl.release(); ctx->mask.release(); ctx->aux0.release(); ctx->aux1.release();
     ctx->wl_rec.release(); ctx->wl_count.release();
+    ctx->deep_entries.release(); ctx->deep_ctl.release(); ctx->deep_sched.release(); ctx->deep_partials.release();
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->d_binom) (void)hipFree(ctx->d_binom);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
@@ -353,6 +356,10 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
         if (value < 1) return fail(P2S_ERR_INVALID_ARG, "max subsets per level must be >= 1");
         ctx->max_subsets = (uint32_t)value;
         return P2S_OK;
+    case P2S_TUNE_DEEP_MIN_SUBSETS:
+        if (value < 0) return fail(P2S_ERR_INVALID_ARG, "deep-level threshold must be >= 0");
+        ctx->deep_min_subsets = (uint32_t)value;
+        return P2S_OK;
     case P2S_TUNE_DIAG_MODE:
 #ifdef P2S_DIAG
         ctx->debug_mode = value;
@@ -469,6 +476,37 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     a.lik_thr = params->likelihood_threshold;
     a.debug_mode = ctx->debug_mode;                                   // 0 unless a -DP2S_DIAG build was told otherwise
 
+    // Deep levels: can a level of this camera count exceed the threshold at all?  Then units about to enter one are
+    // exported by the search kernel and finished by rounds of plan / eval / reduce over the whole GPU, chunk by chunk
+    // (the host reads a 4-byte count per round, so these calls synchronise the stream).
+    bool deep = false;
+    P2sDeepArgs dargs{};
+    constexpr uint32_t kDeepCapacity = 16384, kDeepTickets = 1u << 17;
+    if (ctx->deep_min_subsets > 0) {
+        std::vector<uint32_t> b(33 * 33);
+        fill_binom(b.data());
+        for (int k = 1; k <= C - params->min_cameras; ++k) deep = deep || b[C * 33 + k] > ctx->deep_min_subsets;
+    }
+    if (deep) {
+        if ((uint64_t)ctx->max_subsets > (uint64_t)kDeepTickets * P2S_DEEP_CHUNK)
+            return fail(P2S_ERR_INVALID_ARG, "max subsets per level exceeds the deep-level ticket buffer");
+        const uint32_t obs_bytes = (uint32_t)(rec_bytes - P2S_REC_HDR);
+        const uint32_t entry_bytes = (uint32_t)((sizeof(P2sDeepEntry) + obs_bytes + 15) / 16 * 16);
+        if ((rc = ctx->deep_entries.ensure((size_t)kDeepCapacity * entry_bytes)) != P2S_OK) return rc;
+        if ((rc = ctx->deep_ctl.ensure(64)) != P2S_OK) return rc;
+        if ((rc = ctx->deep_sched.ensure((size_t)kDeepTickets * 2 * sizeof(uint32_t))) != P2S_OK) return rc;
+        if ((rc = ctx->deep_partials.ensure((size_t)kDeepTickets * sizeof(P2sDeepPartial))) != P2S_OK) return rc;
+        dargs.entries = (unsigned char *)ctx->deep_entries.p;
+        dargs.ctl = (uint32_t *)ctx->deep_ctl.p;
+        dargs.sched_entry = (uint32_t *)ctx->deep_sched.p;
+        dargs.sched_chunk = dargs.sched_entry + kDeepTickets;
+        dargs.partials = (P2sDeepPartial *)ctx->deep_partials.p;
+        dargs.capacity = kDeepCapacity; dargs.max_tickets = kDeepTickets;
+        dargs.entry_bytes = entry_bytes; dargs.obs_bytes = obs_bytes;
+        a.deep_entries = dargs.entries; a.deep_ctl = dargs.ctl;
+        a.deep_capacity = kDeepCapacity; a.deep_entry_bytes = entry_bytes; a.deep_min_subsets = ctx->deep_min_subsets;
+    }
+
     for (int64_t ch = 0; ch < n_chunks; ++ch) {
         a.block0 = ch * chunk_blocks;
         a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - a.block0);
@@ -487,13 +525,25 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         L.lds1 = lds1;
         L.force_tiled = ctx->force_tiled;                    // p2s_set_tuning: tests of the tiled kernel
         const int slot = (int)(ch & 1);
-        const bool overlap = n_chunks > 1 && !ctx->no_overlap;
+        const bool overlap = n_chunks > 1 && !ctx->no_overlap && !deep;
+        if (deep) HIP_TRY(hipMemsetAsync(dargs.ctl, 0, 64, ctx->stream));
         hipStream_t side = overlap ? ctx->side_stream : ctx->stream;
         if (overlap && ch >= 2) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[slot], 0));   // list `slot` is free again
         HIP_TRY(p2s_launch_tri(a, dtype, L, ctx->stream, side, ctx->ev_k1[slot]));
         if (overlap) HIP_TRY(hipEventRecord(ctx->ev_k2[slot], side));
+        if (deep) {
+            uint32_t pending = 0;
+            HIP_TRY(hipMemcpyAsync(&pending, dargs.ctl + P2S_DEEP_N_ENTRIES, sizeof pending, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const int deep_lds = lds_rec_off + 4 * (int)dargs.obs_bytes;
+            while (pending > 0) {
+                HIP_TRY(p2s_launch_deep_round(a, dargs, dtype, 256 * 3, deep_lds, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(&pending, dargs.ctl + P2S_DEEP_PENDING, sizeof pending, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+            }
+        }
     }
-    if (n_chunks > 1 && !ctx->no_overlap) {   // join: the caller's stream sees every search finished
+    if (n_chunks > 1 && !ctx->no_overlap && !deep) {   // join: the caller's stream sees every search finished
         HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[(n_chunks - 1) & 1], 0));
         if (n_chunks > 1) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_k2[(n_chunks - 2) & 1], 0));
     }

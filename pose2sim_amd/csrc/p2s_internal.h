@@ -62,11 +62,45 @@ struct P2sTriArgs {
     int32_t K, C, FB;
     int32_t lds_binom_off, lds_rec_off;   // kernel 2 LDS layout: [P][binom][records]
     int32_t min_cams, undistort, lr_swap;
+    unsigned char *deep_entries; // search kernel: units about to enter a level of more than deep_min_subsets subsets are
+    uint32_t *deep_ctl;          //   exported here (NULL: every level is walked in the wave)
+    uint32_t deep_capacity, deep_entry_bytes, deep_min_subsets;
     uint32_t max_subsets;        // search kernel: a level with more subsets is not entered (P2S_MAX_SUBSETS_PER_LEVEL unless tuned)
     int32_t job;                 // work-list records a search wave takes at a time (<= 64); sizes its LDS region
     int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
     double thr, lik_thr;
 };
+
+// ---- deep levels of the search, spread over the GPU (p2s_tri_deep.hip) ----------------------------------------------
+#define P2S_DEEP_CHUNK 16384u            // consecutive subset ranks one wave evaluates per ticket (256 rounds of 64 lanes)
+#define P2S_DEEP_MIN_SUBSETS 16384u      // a level with more subsets than this leaves the search kernel's wave
+#define P2S_DEEP_N_ENTRIES 0             // ctl words
+#define P2S_DEEP_N_TICKETS 1
+#define P2S_DEEP_TICKET 2
+#define P2S_DEEP_PENDING 3
+#define P2S_DEEP_WAITING 0u              // entry states
+#define P2S_DEEP_SCHEDULED 1u
+#define P2S_DEEP_DONE 2u
+struct P2sDeepEntry {                    // followed by the unit's observations as in its work-list record
+    uint32_t unit, level;                // unit id within the chunk; level to evaluate next
+    int32_t Lmax;
+    uint32_t nanmask, zeromask, mask, n_excl, state;
+    uint32_t first_ticket, n_chunks, pad0, pad1;
+    double err_min, Q[3];                // best of the last level (reporting only: a deeper level replaces it)
+    double N[10];                        // level-0 normal matrix
+};
+struct P2sDeepPartial {                  // best plain and best swap candidate of one chunk
+    double e, q[3], se, sq[3];
+    uint32_t rank, S, srank, sS;
+};
+struct P2sDeepArgs {
+    unsigned char *entries;
+    uint32_t *ctl;
+    uint32_t *sched_entry, *sched_chunk;
+    P2sDeepPartial *partials;
+    uint32_t capacity, max_tickets, entry_bytes, obs_bytes;
+};
+hipError_t p2s_launch_deep_round(const struct P2sTriArgs &a, const P2sDeepArgs &d, int dtype, int grid_eval, int lds, hipStream_t s);
 
 struct P2sTriLaunch {
     int grid0, threads0, lds0;   // level-0 (streaming) kernel

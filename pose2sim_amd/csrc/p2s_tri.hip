@@ -638,8 +638,27 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                     // runs) is not entered -- the reference would need hours of CPU for that one keypoint; the unit
                     // ends as "not triangulated" and is counted (p2s_get_tri_stats)
                     const bool more = (err_min > thr) && (level + 1 <= Lmax) && (P2S_DEBUG_MODE(a) != 3);
-                    cont = more && (sBinom[C * 33 + level + 1] <= a.max_subsets);
+                    const uint32_t nsub_next = more ? sBinom[C * 33 + level + 1] : 0u;
+                    cont = more && (nsub_next <= a.max_subsets);
                     capped = capped || (more && !cont);
+                    if (cont && a.deep_entries && nsub_next > a.deep_min_subsets) {
+                        // the next level is too long for one wave: hand the unit to the deep rounds (p2s_tri_deep.hip)
+                        const uint32_t slot = atomicAdd(a.deep_ctl + P2S_DEEP_N_ENTRIES, 1u);
+                        if (slot < a.deep_capacity) {
+                            unsigned char *dst = a.deep_entries + (size_t)slot * a.deep_entry_bytes;
+                            P2sDeepEntry *de = reinterpret_cast<P2sDeepEntry *>(dst);
+                            de->unit = u; de->level = (uint32_t)(level + 1); de->Lmax = Lmax;
+                            de->nanmask = nanmask; de->zeromask = zeromask; de->mask = mask; de->n_excl = (uint32_t)n_excl;
+                            de->state = P2S_DEEP_WAITING; de->first_ticket = 0; de->n_chunks = 0; de->pad0 = de->pad1 = 0;
+                            de->err_min = err_min; de->Q[0] = Qb[0]; de->Q[1] = Qb[1]; de->Q[2] = Qb[2];
+                            const double *sN = reinterpret_cast<const double *>(states + (size_t)lane * 96);
+                            for (int i = 0; i < 10; ++i) de->N[i] = sN[i];
+                            const uint32_t *src = reinterpret_cast<const uint32_t *>(myrec + P2S_REC_HDR);
+                            uint32_t *od = reinterpret_cast<uint32_t *>(dst + sizeof(P2sDeepEntry));
+                            for (int i = 0; i < ((a.rec_bytes - P2S_REC_HDR) >> 2); ++i) od[i] = src[i];
+                            cont = false;
+                        }
+                    }
                 }
             }
             pend_level = __ballot(cont);

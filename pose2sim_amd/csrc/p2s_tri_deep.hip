@@ -1,0 +1,267 @@
+// p2s_tri_deep.hip -- deep levels of the camera-subset search, spread over the whole GPU.
+//
+// With many cameras a single unit can reach a level of millions of subsets (C(32, 8) = 10.5 M, C(32, 10) = 64.5 M).
+// The work-list search kernel (p2s_tri.hip) walks a unit's level inside ONE wave: such a unit keeps that wave busy for
+// seconds while the rest of the chip has long finished -- on the 32-camera shard of BASELINE configs[4] the whole step
+// took as long as its worst unit (2 - 6 s for ~0.1 s of aggregate arithmetic).  Here a level with more than
+// `deep_min_subsets` subsets is cut into chunks of P2S_DEEP_CHUNK consecutive ranks (itertools.combinations order),
+// one wave per chunk:
+//
+//   search kernel   a unit about to enter such a level is exported: its record, level-0 normal matrix, masks and
+//                   best-so-far go to the deep list (p2s_tri.hip)
+//   plan            one workgroup lays the pending entries' chunks out as tickets, as many entries as fit the
+//                   partial-result buffer (the others wait for the next round)
+//   eval            persistent waves draw tickets; lane j of a wave evaluates ranks chunk0 + 64 i + j: normal matrix
+//                   minus the removed cameras, eigen-solve, reprojection error, L/R-swap candidate -- the arithmetic
+//                   of the search kernel -- and the wave's best plain and best swap candidate (lowest rank on ties)
+//                   become the chunk's partial result
+//   reduce          one wave per entry: argmin over its chunks, then the level's bookkeeping exactly as the search
+//                   kernel does it (triangulation.py:500-505, 509-579, 588-604); the unit is finished (results
+//                   stored) or moves to its next level
+//
+// and the host repeats plan / eval / reduce until no entry is pending (one 4-byte read per round).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "p2s_internal.h"
+#include "p2s_tri_dev.h"
+
+namespace {
+
+constexpr uint32_t kNone = 0xffffffffu;
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ P2sDeepEntry *entry_at(const P2sDeepArgs &d, uint32_t i) {
+    return reinterpret_cast<P2sDeepEntry *>(d.entries + (size_t)i * d.entry_bytes);
+}
+
+// ---- plan: tickets for the entries that fit this round ------------------------------------------------------------------
+__global__ void __launch_bounds__(64) p2s_deep_plan_kernel(const P2sDeepArgs d, const uint32_t *binom, int C) {
+    if (threadIdx.x != 0) return;
+    const uint32_t n = min(d.ctl[P2S_DEEP_N_ENTRIES], d.capacity);
+    uint32_t tickets = 0, scheduled = 0, pending = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        P2sDeepEntry *e = entry_at(d, i);
+        if (e->state == P2S_DEEP_DONE) continue;
+        ++pending;
+        const uint32_t nsub = binom[C * 33 + e->level];
+        const uint32_t chunks = (nsub + P2S_DEEP_CHUNK - 1) / P2S_DEEP_CHUNK;
+        if (tickets + chunks > d.max_tickets && scheduled > 0) { e->state = P2S_DEEP_WAITING; continue; }
+        // (a single entry never exceeds the buffer: max_tickets >= max_subsets / P2S_DEEP_CHUNK, checked on the host)
+        e->state = P2S_DEEP_SCHEDULED;
+        e->first_ticket = tickets;
+        e->n_chunks = chunks;
+        for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[tickets + c] = i; d.sched_chunk[tickets + c] = c; }
+        tickets += chunks;
+        ++scheduled;
+    }
+    d.ctl[P2S_DEEP_N_TICKETS] = tickets;
+    d.ctl[P2S_DEEP_TICKET] = 0;
+    d.ctl[P2S_DEEP_PENDING] = pending;                      // the reduce kernel takes the finished ones off
+}
+
+// ---- eval: one chunk of one entry's level per ticket ----------------------------------------------------------------------
+// LDS per wave: [P: C*12 doubles][binom: 33*33 u32] shared by the workgroup, then per wave the entry's observations.
+template <typename T, bool UNDISTORT, bool LRSWAP>
+__global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs a, const P2sDeepArgs d) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int C = a.C;
+    double *sP = reinterpret_cast<double *>(smem);
+    uint32_t *sBinom = reinterpret_cast<uint32_t *>(smem + a.lds_binom_off);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T *sObs = reinterpret_cast<T *>(smem + a.lds_rec_off + (size_t)wave * d.obs_bytes);
+    cam_cptr cams = (cam_cptr)a.cams;
+    for (int i = tid; i < C * 12; i += blockDim.x) sP[i] = a.cams[i / 12].P[i % 12];
+    for (int i = tid; i < 33 * 33; i += blockDim.x) sBinom[i] = a.binom[i];
+    __syncthreads();
+    const double thr = a.thr;
+    const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+    const uint32_t n_tickets = d.ctl[P2S_DEEP_N_TICKETS];
+
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(d.ctl + P2S_DEEP_TICKET, 1u);
+        t = __shfl(t, 0, 64);
+        if (t >= n_tickets) break;
+        const P2sDeepEntry *e = entry_at(d, d.sched_entry[t]);
+        const uint32_t chunk = d.sched_chunk[t];
+        const int level = (int)e->level;
+        const uint32_t nsub = sBinom[C * 33 + level];
+        const uint32_t r_begin = chunk * P2S_DEEP_CHUNK, r_end = min(nsub, r_begin + P2S_DEEP_CHUNK);
+        {   // the entry's observations (as the streaming kernel left them in the record) -> this wave's LDS
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(reinterpret_cast<const unsigned char *>(e) + sizeof(P2sDeepEntry));
+            uint32_t *dst = reinterpret_cast<uint32_t *>(sObs);
+            for (int i = lane; i < (int)(d.obs_bytes >> 2); i += 64) dst[i] = src[i];
+        }
+        wave_sync();
+        UnitObs<T> oobs{sObs, 3, a.lik_thr};
+        UnitObs<T> oobs_sw = oobs;
+        if (LRSWAP) oobs_sw.p = sObs + C * 3;
+        const uint32_t o_nan = e->nanmask, o_d = e->nanmask | e->zeromask, o_valid = allmask & ~o_d;
+        const int oV = __popc(o_d);
+        const int M = C - oV - level;                       // cameras left when `level` valid ones go (:437, 513)
+        double oN[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) oN[i] = e->N[i];
+
+        double be = kInf, bq0 = d_nan(), bq1 = d_nan(), bq2 = d_nan();
+        uint32_t brank = kNone, bS = 0;
+        double se = kInf, sq0 = d_nan(), sq1 = d_nan(), sq2 = d_nan();
+        uint32_t srank = kNone, sS = 0;
+        for (uint32_t r0 = r_begin; r0 < r_end; r0 += 64) {
+            const uint32_t r = r0 + lane;
+            bool go = r < r_end;
+            uint32_t S = 0;
+            if (go) {
+                S = unrank_subset(r, C, level, sBinom);
+                // duplicates of one effective configuration (quirk Q1): only the lexicographically first one -- padding =
+                // the lowest cameras of the excluded set -- can win
+                const uint32_t pad = S & o_d;
+                const uint32_t below = pad ? ((2u << (31 - __builtin_clz(pad))) - 1u) : 0u;
+                go = (o_d & below) == pad;
+            }
+            if (!__any(go)) continue;
+            const uint32_t Rreal = S & o_valid;
+            const uint32_t kept = o_valid & ~Rreal;
+            const int nkept = __popc(kept);
+            double Ns[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) Ns[i] = oN[i];
+            for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                const int c = rr ? __builtin_ctz(rr) : 0;
+                double x, y, w;
+                oobs.raw(c, x, y, w);
+                const bool on = rr != 0u;
+                accum_camera<-1>(Ns, sP + c * 12, on ? x : 0.0, on ? y : 0.0, on ? w : 0.0);
+            }
+            double q[3];
+            smallest_eigvec(Ns, q);
+            if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
+            const double err = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
+            if (go && (err < be || brank == kNone)) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
+            if (LRSWAP && M > 2) {
+                // the swap candidate counts only if the level's plain minimum stays above the threshold, which no
+                // single wave knows: every chunk evaluates it, the reduction decides (triangulation.py:509)
+                double qs[3];
+                const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                if (go && (es < se || srank == kNone)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
+            }
+        }
+        // wave argmin, lowest rank on ties (np.nanargmin / np.argmin)
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oe = shfl_d(be, lane ^ off);
+            const uint32_t orank = __shfl(brank, lane ^ off, 64);
+            const bool take = (orank != kNone) && (brank == kNone || oe < be || (oe == be && orank < brank));
+            const double t0 = shfl_d(bq0, lane ^ off), t1 = shfl_d(bq1, lane ^ off), t2 = shfl_d(bq2, lane ^ off);
+            const uint32_t tS = __shfl(bS, lane ^ off, 64);
+            if (take) { be = oe; brank = orank; bq0 = t0; bq1 = t1; bq2 = t2; bS = tS; }
+            if (LRSWAP) {
+                const double xe = shfl_d(se, lane ^ off);
+                const uint32_t xrank = __shfl(srank, lane ^ off, 64);
+                const bool tk = (xrank != kNone) && (srank == kNone || xe < se || (xe == se && xrank < srank));
+                const double s0 = shfl_d(sq0, lane ^ off), s1 = shfl_d(sq1, lane ^ off), s2 = shfl_d(sq2, lane ^ off);
+                const uint32_t xS = __shfl(sS, lane ^ off, 64);
+                if (tk) { se = xe; srank = xrank; sq0 = s0; sq1 = s1; sq2 = s2; sS = xS; }
+            }
+        }
+        if (lane == 0) {
+            P2sDeepPartial &p = d.partials[t];
+            p.e = be; p.q[0] = bq0; p.q[1] = bq1; p.q[2] = bq2; p.rank = brank; p.S = bS;
+            p.se = se; p.sq[0] = sq0; p.sq[1] = sq1; p.sq[2] = sq2; p.srank = srank; p.sS = sS;
+        }
+        wave_sync();                                        // the next ticket overwrites this wave's LDS region
+    }
+}
+
+// ---- reduce: the level's result of every scheduled entry -------------------------------------------------------------------
+template <bool LRSWAP>
+__global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a, const P2sDeepArgs d) {
+    const int C = a.C;
+    const uint32_t n = min(d.ctl[P2S_DEEP_N_ENTRIES], d.capacity);
+    const int lane = threadIdx.x;
+    const double thr = a.thr;
+    const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        P2sDeepEntry *e = entry_at(d, i);
+        if (e->state != P2S_DEEP_SCHEDULED) continue;
+        double be = kInf, se = kInf;
+        uint32_t brank = kNone, srank = kNone, bt = 0, st = 0;         // bt / st: ticket holding the candidate
+        for (uint32_t c = lane; c < e->n_chunks; c += 64) {
+            const P2sDeepPartial &p = d.partials[e->first_ticket + c];
+            if (p.rank != kNone && (brank == kNone || p.e < be || (p.e == be && p.rank < brank))) { be = p.e; brank = p.rank; bt = e->first_ticket + c; }
+            if (LRSWAP && p.srank != kNone && (srank == kNone || p.se < se || (p.se == se && p.srank < srank))) { se = p.se; srank = p.srank; st = e->first_ticket + c; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double oe = shfl_d(be, lane ^ off);
+            const uint32_t orank = __shfl(brank, lane ^ off, 64), ot = __shfl(bt, lane ^ off, 64);
+            if ((orank != kNone) && (brank == kNone || oe < be || (oe == be && orank < brank))) { be = oe; brank = orank; bt = ot; }
+            if (LRSWAP) {
+                const double xe = shfl_d(se, lane ^ off);
+                const uint32_t xrank = __shfl(srank, lane ^ off, 64), xt = __shfl(st, lane ^ off, 64);
+                if ((xrank != kNone) && (srank == kNone || xe < se || (xe == se && xrank < srank))) { se = xe; srank = xrank; st = xt; }
+            }
+        }
+        if (lane != 0) continue;
+        // the level's result, as in the search kernel (triangulation.py:500-505, 509-579)
+        const uint32_t o_nan = e->nanmask, o_d = e->nanmask | e->zeromask, o_valid = allmask & ~o_d;
+        const int oV = __popc(o_d);
+        const int level = (int)e->level;
+        const int M = C - oV - level;
+        const P2sDeepPartial &pb = d.partials[bt];
+        double l_err = be, l_q0 = pb.q[0], l_q1 = pb.q[1], l_q2 = pb.q[2];
+        uint32_t l_mask = o_nan | pb.S;
+        const uint32_t l_nexcl = (uint32_t)(oV + __popc(pb.S & o_valid));            // :436 counts NaN or zero
+        if (LRSWAP && l_err > thr && M > 2 && srank != kNone && se < l_err) {        // :576-579, nb_cams_excluded NOT updated
+            const P2sDeepPartial &ps = d.partials[st];
+            l_err = se; l_q0 = ps.sq[0]; l_q1 = ps.sq[1]; l_q2 = ps.sq[2]; l_mask = o_nan | ps.sS;
+        }
+        e->err_min = l_err; e->Q[0] = l_q0; e->Q[1] = l_q1; e->Q[2] = l_q2; e->mask = l_mask; e->n_excl = l_nexcl;
+        const bool more = (l_err > thr) && (level + 1 <= e->Lmax);
+        const bool cont = more && (a.binom[C * 33 + level + 1] <= a.max_subsets);
+        if (more && !cont && a.stats) atomicAdd(a.stats + 3, 1ull);                  // stopped by the safety valve
+        if (a.stats) { atomicAdd(a.stats + 1, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 2, (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64)); }
+        if (cont) {
+            e->level = (uint32_t)(level + 1);
+            e->state = P2S_DEEP_WAITING;
+        } else {                                                                     // triangulation.py:588-604
+            const int64_t gu = a.block0 * a.K + e->unit;
+            const bool fail = !(l_err <= thr);
+            double *Qo = a.Q + gu * 3;
+            Qo[0] = fail ? d_nan() : l_q0; Qo[1] = fail ? d_nan() : l_q1; Qo[2] = fail ? d_nan() : l_q2;
+            a.err[gu] = fail ? __builtin_nanf("") : (float)l_err;
+            a.n_excl[gu] = (uint8_t)l_nexcl;
+            a.mask[gu] = l_mask;
+            e->state = P2S_DEEP_DONE;
+            atomicSub(d.ctl + P2S_DEEP_PENDING, 1u);
+        }
+    }
+}
+
+template <typename T, bool U, bool L>
+hipError_t launch_round(const P2sTriArgs &a, const P2sDeepArgs &d, int grid_eval, int lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_deep_eval_kernel<T, U, L>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(p2s_deep_plan_kernel, dim3(1), dim3(64), 0, s, d, a.binom, a.C);
+    hipLaunchKernelGGL((p2s_deep_eval_kernel<T, U, L>), dim3(grid_eval), dim3(256), lds, s, a, d);
+    hipLaunchKernelGGL((p2s_deep_reduce_kernel<L>), dim3(256), dim3(64), 0, s, a, d);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t p2s_launch_deep_round(const P2sTriArgs &a, const P2sDeepArgs &d, int dtype, int grid_eval, int lds, hipStream_t s) {
+    const bool U = a.undistort != 0, L = a.lr_swap != 0;
+    if (dtype == 0) {
+        if (U) return L ? launch_round<float, true, true>(a, d, grid_eval, lds, s) : launch_round<float, true, false>(a, d, grid_eval, lds, s);
+        return L ? launch_round<float, false, true>(a, d, grid_eval, lds, s) : launch_round<float, false, false>(a, d, grid_eval, lds, s);
+    }
+    if (U) return L ? launch_round<double, true, true>(a, d, grid_eval, lds, s) : launch_round<double, true, false>(a, d, grid_eval, lds, s);
+    return L ? launch_round<double, false, true>(a, d, grid_eval, lds, s) : launch_round<double, false, false>(a, d, grid_eval, lds, s);
+}

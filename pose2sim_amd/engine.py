@@ -88,7 +88,7 @@ class Engine:
         _lib.check(self._lib.p2s_synchronize(self._h))
 
     # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
-    TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS = 1, 2, 3, 4, 5, 6
+    TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS, TUNE_DEEP_MIN_SUBSETS = 1, 2, 3, 4, 5, 6, 7
     TRI_PATH_AUTO, TRI_PATH_WORKLIST = 0, 1
 
     def tri_stats(self, reset=False):

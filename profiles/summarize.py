@@ -15,9 +15,10 @@ os.makedirs(DST, exist_ok=True)
 
 
 def short(name):
+    name = name.replace('void ', '').replace('(anonymous namespace)::', '')
     name = name.split('(')[0]
     name = name.split('<')[0]
-    return name.replace('void ', '').strip()
+    return name.strip()
 
 
 def counter_avg(subdir, counter):

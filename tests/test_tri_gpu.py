@@ -378,3 +378,45 @@ def test_search_valve_boundary():
         assert (ref[2][differ] >= 4).all()                      # the full search went on to level 4 for exactly these units
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('C,min_cams,lr_swap,undistort,f64', [
+    (8, 2, False, False, False),
+    (9, 2, True, False, False),
+    (7, 2, True, True, False),
+    (12, 3, False, False, True),
+])
+def test_deep_levels_spread_over_the_gpu(C, min_cams, lr_swap, undistort, f64):
+    """Levels with more subsets than the deep threshold leave the search kernel's wave and are evaluated chunk by
+    chunk by the whole GPU (p2s_tri_deep.hip: plan / eval / reduce rounds).  With the threshold lowered to 10 subsets
+    every level from the second on takes that road (several rounds per unit, L/R swap candidates and undistortion
+    included): every unit against the C oracle, and bit-identical to the all-in-one-wave search."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from oracle import tri_oracle
+    from pose2sim_amd import skeletons, synth
+    from pose2sim_amd.engine import Engine
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    wl = synth.make_config(1500, C, 26, 1, seed=300 + C, undistort=undistort, lr_swap=lr_swap, swap_idx=swap,
+                           p_outlier=0.12, p_lowlik=0.05, p_missing_cam=0.02)
+    x64 = wl['xyl'].astype(np.float64) + (1e-9 if f64 else 0.0)
+    x = x64 if f64 else wl['xyl']
+    eng = Engine(0)
+    try:
+        eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST)
+        eng.set_calibration(wl['P'], wl['cams'] if undistort else None)
+        prm = eng.tri_params(8.0, 0.3, min_cams, undistort, lr_swap)
+        eng.set_tuning(Engine.TUNE_DEEP_MIN_SUBSETS, 0)
+        ref = eng.triangulate(x, prm, swap if lr_swap else None)
+        eng.set_tuning(Engine.TUNE_DEEP_MIN_SUBSETS, 10)
+        eng.tri_stats(reset=True)
+        got = eng.triangulate(x, prm, swap if lr_swap else None)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b, equal_nan=True)
+        threads = min(64, len(os.sched_getaffinity(0)))
+        Qr, er, nr, mr = tri_oracle.triangulate_batch(x64, wl['P'], wl['cams'] if undistort else None, swap, 0.3, 8.0, min_cams,
+                                                      lr_swap, undistort, threads=threads)
+        _compare(got[0], got[1], got[2], got[3], Qr, er, nr, mr, f'deep C={C}')
+        assert (nr.reshape(-1) - np.isnan(x64[..., 2]).sum(axis=2).reshape(-1) >= 2).any()     # some unit did go past level 1
+    finally:
+        eng.close()
