@@ -199,17 +199,18 @@ __global__ void __launch_bounds__(64, (CT <= 8 ? 3 : 2)) p2s_tri_fused_kernel(co
         const unsigned long long lt = (1ull << lane) - 1ull;
         const int n_hard = __popcll(hard);
         const int my_ord = __popcll(hard & lt);
+        // the first kSlots searching units take their slots here, straight from registers (N dies with this write: left
+        // inside the rounds loop it was spilled to scratch around it, 130 MB of HBM writes per cfg2 step)
+        if (need && my_ord < kSlots) {
+            slot_t &s = slots[my_ord];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s.N[i] = N[i];
+            s.nan = nanmask; s.zero = zeromask; s.owner = (uint32_t)lane;
+        }
         for (int first = 0; first < n_hard; first += kSlots) {             // rounds of at most kSlots units
             const bool mine = need && my_ord >= first && my_ord < first + kSlots;
             const int my_slot = mine ? my_ord - first : 0;
-            if (first == 0) {
-                if (mine) {
-                    slot_t &s = slots[my_slot];
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) s.N[i] = N[i];
-                    s.nan = nanmask; s.zero = zeromask; s.owner = (uint32_t)lane;
-                }
-            } else {
+            if (first > 0) {
                 // more than kSlots searching units in one wave (rare): the later ones rebuild their normal matrix from
                 // the staged observations, so that it need not stay in registers across the search
                 wave_sync();                                                // the previous round's slots are done with
