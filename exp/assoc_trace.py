@@ -1,13 +1,16 @@
-"""Diagnostics: per-frame phase timeline of the association kernel (P2S_DEBUG_MODE=7)."""
+"""Diagnostics: per-frame phase timeline of the association kernel (kernel diagnostics mode 7 of a -DP2S_DIAG build of the library:
+built here into pose2sim_amd/csrc/libp2s_hip_diag.so and selected through P2S_LIB; the shipped library refuses the mode)."""
 import os, sys
-os.environ['P2S_DEBUG_MODE'] = '7'
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+os.environ['P2S_LIB'] = entry.build_hip(defines=['P2S_DIAG'], lib=os.path.join(ROOT, 'pose2sim_amd', 'csrc', 'libp2s_hip_diag.so'))
 import bench
 from pose2sim_amd.engine import Engine
 cfg = dict(bench.CONFIGS['cfg3']); cfg['F'] = 4000
 xyl, cams, P, swap, K = bench.make_workload(cfg, 0)
 n_persons, kpts = bench.make_association_inputs(xyl, cfg['seed'])
-eng = Engine(0); eng.set_calibration(P, cams)
+eng = Engine(0); eng.set_calibration(P, cams); eng.set_tuning(Engine.TUNE_DIAG_MODE, 7)
 aff = eng.associate(n_persons, kpts, Engine.assoc_params(0.1, 0.2, 2))
 t = aff.reshape(aff.shape[0], -1)[:, :8]
 tot = t[:, 0].mean()

@@ -1,7 +1,10 @@
-"""Diagnostics: per-wave timeline of the search kernel (P2S_DEBUG_MODE=5)."""
+"""Diagnostics: per-wave timeline of the work-list search kernel (kernel diagnostics mode 5 of a -DP2S_DIAG build of the library:
+built here into pose2sim_amd/csrc/libp2s_hip_diag.so and selected through P2S_LIB; the shipped library refuses the mode)."""
 import os, sys
-os.environ['P2S_DEBUG_MODE'] = '5'
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+os.environ['P2S_LIB'] = entry.build_hip(defines=['P2S_DIAG'], lib=os.path.join(ROOT, 'pose2sim_amd', 'csrc', 'libp2s_hip_diag.so'))
 import numpy as np, torch
 import bench
 from pose2sim_amd.engine import Engine, P2S_F32
@@ -10,6 +13,7 @@ xyl, cams, P, swap, K = bench.make_workload(cfg, 0)
 F, Pn, C = xyl.shape[:3]
 dev = torch.device('cuda', 0)
 eng = Engine(0); eng.set_calibration(P, cams); eng.set_stream(torch.cuda.current_stream().cuda_stream)
+eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST); eng.set_tuning(Engine.TUNE_DIAG_MODE, 5)
 prm = eng.tri_params(cfg['thr'], cfg['lik'], cfg['min_cams'], False, False)
 d = torch.from_numpy(np.ascontiguousarray(xyl.reshape(F * Pn, C, K, 3))).to(dev)
 n = F * Pn * K
