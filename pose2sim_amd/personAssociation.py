@@ -320,8 +320,17 @@ def associate_all(config_dict):
         names = [[maps[c].get(f, 'none') for c in range(n_cams)] for f in frames]
         frames_src = [[os.path.join(pose_dir, json_dirs_names[c], nm[c]) for c in range(n_cams)] for nm in names]
         frames_dst = [[os.path.join(poseTracked_dir, json_dirs_names[c], nm[c]) for c in range(n_cams)] for nm in names]
-        error_min_tot, cameras_off_tot = _associate_single_person(config_dict, frames_src, frames_dst, n_cams,
-                                                                  P_all, calib_params)
+        # whatever this rank's share raises is agreed with the others BEFORE the collective: all ranks raise together
+        # instead of one leaving and the rest waiting in the gather
+        error_min_tot, cameras_off_tot, failure = [], [], None
+        try:
+            error_min_tot, cameras_off_tot = _associate_single_person(config_dict, frames_src, frames_dst, n_cams,
+                                                                      P_all, calib_params)
+        except Exception as exc:                           # noqa: BLE001 -- re-raised on every rank by agree_ok
+            if world == 1:
+                raise
+            failure = exc
+        parallel.agree_ok(failure)
         error_min_tot, cameras_off_tot = parallel.gather_lists(error_min_tot, cameras_off_tot)   # recap over all frames
         if rank == 0:
             recap_tracking(config_dict, error_min_tot, cameras_off_tot)

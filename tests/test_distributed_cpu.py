@@ -194,3 +194,52 @@ def test_two_ranks_associate_their_own_frames(golden_dir, tmp_path, multi):
     assert sorted(got) == sorted(want)
     for k in want:
         assert got[k] == want[k], k
+
+
+def test_collectives_use_the_local_rank_gpu(monkeypatch):
+    """With RCCL the operands of every collective live on cuda:LOCAL_RANK -- the device the engine takes -- and not on
+    torch's current device, which is cuda:0 in every rank unless somebody called set_device."""
+    import torch
+    import torch.distributed as dist
+    from pose2sim_amd import parallel
+    monkeypatch.setattr(dist, 'get_backend', lambda *a, **k: 'nccl')
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert parallel.collective_device() == torch.device('cuda', 3)
+    monkeypatch.setattr(dist, 'get_backend', lambda *a, **k: 'gloo')
+    assert parallel.collective_device() == torch.device('cpu')
+
+
+def test_ranks_without_a_process_group_are_refused(monkeypatch):
+    """WORLD_SIZE > 1 with no initialised process group would make every rank take every frame and write the same
+    files: dist_info refuses."""
+    from pose2sim_amd import parallel
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(RuntimeError, match='not initialised'):
+        parallel.dist_info()
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    assert parallel.dist_info() == (0, 1)
+
+
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from pose2sim_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        parallel.agree_ok(ValueError('rank 1 cannot read its files') if rank == 1 else None)
+        outcome = 'no error'
+    except ValueError as e:
+        outcome = f'own: {e}'
+    except RuntimeError as e:
+        outcome = f'other: {e}'
+    with open(os.path.join(out_dir, f'agree{rank}.txt'), 'w') as fh:
+        fh.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_makes_every_rank_raise(tmp_path):
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / 'agree1.txt').read().startswith('own: rank 1 cannot read')
+    assert open(tmp_path / 'agree0.txt').read().startswith('other: another rank failed')

@@ -29,6 +29,19 @@ SCRIPT = textwrap.dedent('''
     gathered = parallel.sharded_triangulate(lambda x: eng.triangulate(x, prm), wl['xyl'])
     for a, b in zip(direct, gathered):
         assert np.array_equal(a, b, equal_nan=True)
+    # the product path's form: results stay on the GPU in one packed buffer (Engine.triangulate_packed), the all-gather
+    # takes that buffer as it is and the host copy happens once
+    F, Pn, K = wl['xyl'].shape[0], wl['xyl'].shape[1], wl['xyl'].shape[3]
+    packed = eng.triangulate_packed(wl['xyl'], prm, pad_blocks=(F + 5) * Pn)       # padded like a largest shard
+    assert packed.buf.is_cuda and packed.n_blocks == F * Pn
+    Qd, ed, nd, md = parallel.unpack_results(packed.buf.cpu().numpy(), (F + 5) * Pn, K)
+    assert np.array_equal(Qd[:F * Pn].reshape(direct[0].shape), direct[0], equal_nan=True)
+    assert np.array_equal(ed[:F * Pn].reshape(direct[1].shape), direct[1], equal_nan=True)
+    assert np.array_equal(nd[:F * Pn].reshape(direct[2].shape), direct[2]) and np.array_equal(md[:F * Pn].reshape(direct[3].shape), direct[3])
+    exact = eng.triangulate_packed(wl['xyl'], prm, pad_blocks=F * Pn)
+    whole = parallel.gather_results(exact, F, Pn, K, host_copy_on=0)
+    for a, b in zip(direct, whole):
+        assert np.array_equal(np.asarray(a).reshape(np.asarray(b).shape), b, equal_nan=True)
     # bench.py's form: packed device buffer, asynchronous all-gather into a second buffer
     n = 1 << 20
     src = torch.arange(n, dtype=torch.int64, device='cuda').to(torch.uint8)
