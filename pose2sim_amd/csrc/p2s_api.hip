@@ -481,7 +481,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     // (the host reads a 4-byte count per round, so these calls synchronise the stream).
     bool deep = false;
     P2sDeepArgs dargs{};
-    constexpr uint32_t kDeepCapacity = 16384, kDeepTickets = 1u << 17;
+    constexpr uint32_t kDeepCapacity = 1u << 19, kDeepTickets = 1u << 20;
     if (ctx->deep_min_subsets > 0) {
         std::vector<uint32_t> b(33 * 33);
         fill_binom(b.data());

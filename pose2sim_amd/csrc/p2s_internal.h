@@ -73,7 +73,8 @@ struct P2sTriArgs {
 
 // ---- deep levels of the search, spread over the GPU (p2s_tri_deep.hip) ----------------------------------------------
 #define P2S_DEEP_CHUNK 16384u            // consecutive subset ranks one wave evaluates per ticket (256 rounds of 64 lanes)
-#define P2S_DEEP_MIN_SUBSETS 16384u      // a level with more subsets than this leaves the search kernel's wave
+#define P2S_DEEP_MIN_SUBSETS 16384u      // a level with more subsets than this leaves the search kernel's wave (C(32, 4) = 36 k
+                                         // and beyond: 5 % of the units of the 32-camera shard; the deep list holds 2^19)
 #define P2S_DEEP_N_ENTRIES 0             // ctl words
 #define P2S_DEEP_N_TICKETS 1
 #define P2S_DEEP_TICKET 2

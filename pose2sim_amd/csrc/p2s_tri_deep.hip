@@ -41,29 +41,52 @@ __device__ __forceinline__ P2sDeepEntry *entry_at(const P2sDeepArgs &d, uint32_t
     return reinterpret_cast<P2sDeepEntry *>(d.entries + (size_t)i * d.entry_bytes);
 }
 
-// ---- plan: tickets for the entries that fit this round ------------------------------------------------------------------
+// ---- plan: tickets for the entries that fit this round (one wave: 64 entries at a time, exclusive scan of their
+// chunk counts; the first entry always fits, the others while the ticket buffer lasts) -----------------------------------
 __global__ void __launch_bounds__(64) p2s_deep_plan_kernel(const P2sDeepArgs d, const uint32_t *binom, int C) {
-    if (threadIdx.x != 0) return;
+    const int lane = threadIdx.x;
     const uint32_t n = min(d.ctl[P2S_DEEP_N_ENTRIES], d.capacity);
-    uint32_t tickets = 0, scheduled = 0, pending = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        P2sDeepEntry *e = entry_at(d, i);
-        if (e->state == P2S_DEEP_DONE) continue;
-        ++pending;
-        const uint32_t nsub = binom[C * 33 + e->level];
-        const uint32_t chunks = (nsub + P2S_DEEP_CHUNK - 1) / P2S_DEEP_CHUNK;
-        if (tickets + chunks > d.max_tickets && scheduled > 0) { e->state = P2S_DEEP_WAITING; continue; }
-        // (a single entry never exceeds the buffer: max_tickets >= max_subsets / P2S_DEEP_CHUNK, checked on the host)
-        e->state = P2S_DEEP_SCHEDULED;
-        e->first_ticket = tickets;
-        e->n_chunks = chunks;
-        for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[tickets + c] = i; d.sched_chunk[tickets + c] = c; }
-        tickets += chunks;
-        ++scheduled;
+    uint32_t tickets = 0, pending = 0;
+    bool full = false;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        P2sDeepEntry *e = i < n ? entry_at(d, i) : nullptr;
+        const bool live = e && e->state != P2S_DEEP_DONE;
+        pending += (uint32_t)__popcll(__ballot(live));
+        const uint32_t chunks = live ? (binom[C * 33 + e->level] + P2S_DEEP_CHUNK - 1) / P2S_DEEP_CHUNK : 0u;
+        uint32_t incl = chunks;                                             // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        const uint32_t first = tickets + incl - chunks;
+        // an entry is taken while everything before it was taken and it fits (the very first one always: max_tickets >=
+        // max_subsets / P2S_DEEP_CHUNK, checked on the host)
+        const bool fits = live && !full && (first + chunks <= d.max_tickets || first == 0);
+        const unsigned long long fit_mask = __ballot(fits), live_mask = __ballot(live);
+        // the first live entry that does not fit closes the round for everything after it
+        const unsigned long long miss = live_mask & ~fit_mask;
+        const unsigned long long before_miss = miss ? ((miss & (0ull - miss)) - 1ull) : ~0ull;
+        const bool take = fits && ((before_miss >> lane) & 1ull);
+        if (live) e->state = take ? P2S_DEEP_SCHEDULED : P2S_DEEP_WAITING;
+        if (take) {
+            e->first_ticket = first;
+            e->n_chunks = chunks;
+            for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[first + c] = i; d.sched_chunk[first + c] = c; }
+        }
+        const unsigned long long taken = __ballot(take);
+        if (taken) {
+            const int last = 63 - __builtin_clzll(taken);
+            tickets = (uint32_t)__shfl((int)(first + chunks), last, 64);
+        }
+        full = full || (miss != 0ull);
     }
-    d.ctl[P2S_DEEP_N_TICKETS] = tickets;
-    d.ctl[P2S_DEEP_TICKET] = 0;
-    d.ctl[P2S_DEEP_PENDING] = pending;                      // the reduce kernel takes the finished ones off
+    if (lane == 0) {
+        d.ctl[P2S_DEEP_N_TICKETS] = tickets;
+        d.ctl[P2S_DEEP_TICKET] = 0;
+        d.ctl[P2S_DEEP_PENDING] = pending;                  // the reduce kernel takes the finished ones off
+    }
 }
 
 // ---- eval: one chunk of one entry's level per ticket ----------------------------------------------------------------------

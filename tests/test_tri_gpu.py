@@ -94,6 +94,10 @@ def test_golden_units(engine, golden_dir):
     (6, 2, True, True, False),
     (8, 2, False, False, True),
     (3, 2, True, False, True),
+    (4, 2, False, False, True),
+    (2, 2, False, False, True),
+    (13, 4, False, False, False),
+    (16, 2, False, False, False),
 ])
 def test_against_oracle(engine, C, min_cams, lr_swap, undistort, dtype64):
     from oracle import triangulation_ref as tr
