@@ -245,7 +245,12 @@ def _oracle_slice(args):
     """Worker of the process-parallel CPU baseline: the NumPy oracle on one block of frames."""
     xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort = args
     from oracle import triangulation_ref as tr
-    tr.triangulate_batch(xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort)
+    try:                                   # one BLAS thread per process: the pool is the parallel axis
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            tr.triangulate_batch(xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort)
+    except ImportError:
+        tr.triangulate_batch(xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort)
     return xyl.shape[0]
 
 
