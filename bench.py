@@ -241,6 +241,25 @@ def bench_single(args, cfg, rank, world, local_rank):
     print(json.dumps(out), flush=True)
 
 
+def host_cores():
+    """CPUs this process may really use: its affinity mask, cut down to the cgroup's CPU quota where there is one (a
+    one-GPU box shares its host: 256 hardware threads in the mask, 16 CPUs of quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _oracle_slice(args):
     """Worker of the process-parallel CPU baseline: the NumPy oracle on one block of frames."""
     xyl, P, cams, swap, lik, thr, min_cams, lr_swap, undistort = args
@@ -273,7 +292,7 @@ def cpu_baselines(cfg, frames_1core, frames_all):
     cores: what a compiled CPU implementation would reach.  Runs BEFORE anything touches the GPU (fork)."""
     import multiprocessing as mp
     from oracle import triangulation_ref as tr
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = host_cores()
     xyl, cams, P, swap = host_sample(cfg, max(frames_1core, frames_all))
     per_frame = xyl.shape[1] * xyl.shape[3]
     out = {}
@@ -346,8 +365,7 @@ def main():
         entry0.build_oracle()
         # ~2.5 s of single-core work per process: 400 frames at 8 cameras (4.3e3 units/s/core), fewer where a unit is dearer
         f1 = args.cpu_frames or {8: 400, 16: 12, 32: 6}.get(cfg0['C'], 100)
-        n_cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        fall = args.cpu_frames or max(2000 if cfg0['C'] <= 8 else 0, f1 * min(n_cores, 64))
+        fall = args.cpu_frames or max(2000 if cfg0['C'] <= 8 else 0, f1 * min(host_cores(), 64))
         cpu = cpu_baselines(cfg0, f1, max(fall, f1))
 
     import torch
