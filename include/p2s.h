@@ -199,6 +199,8 @@ int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
  *                         2^26; this one DOES change results -- tests of the valve only)
  *   P2S_TUNE_DEEP_MIN_SUBSETS  levels of the work-list search with more camera subsets than this (default 16 384) are
  *                         cut into chunks and spread over the whole GPU instead of being walked by one wave; 0 = never
+ *   P2S_TUNE_ASSOC_FORM   P2S_ASSOC_FORM_AUTO (default): up to 32 detections per frame take the symmetric one-wave kernel;
+ *                         P2S_ASSOC_FORM_GENERAL: the general kernel (no symmetry assumed) at every size
  *   P2S_TUNE_DIAG_MODE    kernel diagnostics of a -DP2S_DIAG build (exp/README.md); refused by the shipped library */
 #define P2S_TUNE_TRI_PATH 1
 #define P2S_TUNE_FORCE_TILED 2
@@ -207,6 +209,9 @@ int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 #define P2S_TUNE_DIAG_MODE 5
 #define P2S_TUNE_MAX_SUBSETS 6
 #define P2S_TUNE_DEEP_MIN_SUBSETS 7
+#define P2S_TUNE_ASSOC_FORM 8
+#define P2S_ASSOC_FORM_AUTO 0
+#define P2S_ASSOC_FORM_GENERAL 1
 #define P2S_TRI_PATH_AUTO 0
 #define P2S_TRI_PATH_WORKLIST 1
 int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value);

@@ -83,6 +83,7 @@ struct p2s_ctx {
     int force_tiled = 0, no_overlap = 0, job = 0;
     uint32_t max_subsets = P2S_MAX_SUBSETS_PER_LEVEL;
     int debug_mode = 0;                              // honoured by a -DP2S_DIAG build only
+    int assoc_form = P2S_ASSOC_FORM_AUTO;
 };
 
 namespace {
@@ -360,6 +361,11 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
         if (value < 0) return fail(P2S_ERR_INVALID_ARG, "deep-level threshold must be >= 0");
         ctx->deep_min_subsets = (uint32_t)value;
         return P2S_OK;
+    case P2S_TUNE_ASSOC_FORM:
+        if (value != P2S_ASSOC_FORM_AUTO && value != P2S_ASSOC_FORM_GENERAL)
+            return fail(P2S_ERR_INVALID_ARG, "unknown association kernel form %d", value);
+        ctx->assoc_form = value;
+        return P2S_OK;
     case P2S_TUNE_DIAG_MODE:
 #ifdef P2S_DIAG
         ctx->debug_mode = value;
@@ -614,6 +620,7 @@ int p2s_associate_device(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, in
     a.n_frames = n_frames; a.C = ctx->n_cams; a.Kj = n_kpts_json; a.Nmax = n_max;
     a.max_iter = params->max_iter;
     a.debug_mode = ctx->debug_mode;
+    a.form = ctx->assoc_form;
     a.recon_thr = params->reconstruction_error_threshold; a.min_affinity = params->min_affinity;
     a.w_rank = params->w_rank; a.tol = params->tol; a.w_sparse = params->w_sparse;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -28,6 +28,16 @@
 
 namespace {
 
+// one Newton step on the v_rcp_f64 / v_rsq_f64 seeds (5e-8 -> 4e-15, exp/seed_precision.hip)
+__device__ __forceinline__ double rcp_1(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    return fma(r, fma(-d, r, 1.0), r);
+}
+__device__ __forceinline__ double rsqrt_1(double t) {
+    const double r = __builtin_amdgcn_rsq(t);
+    return fma(0.5 * r, fma(-t * r, r, 1.0), r);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -79,8 +89,9 @@ __device__ __forceinline__ double block_sum(double v, double *scratch, int tid) 
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    // every lane has a source lane under these controls: bound_ctrl spares the compiler the initialisation of "old"
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 template <int L>
@@ -144,8 +155,11 @@ __device__ void jacobi_svd_t(double *A, double *V, int n, int ld, int lane, int 
             if (__any(rot)) {
                 // Rutishauser's stable formulas; reciprocal / square roots by Newton from the hardware
                 // seeds: the rotation only has to be orthogonal to working precision
-                const double zeta = (be - al) * p2s_rcp(2.0 * ga);
-                const double tt = p2s_rcp(fabs(zeta) + p2s_sqrt(fma(zeta, zeta, 1.0)));
+                // the angle only has to be good enough to annihilate the off-diagonal to ~1e-14 (one Newton step on the
+                // hardware seeds: 4e-15); the rotation's orthogonality hangs on c below, which keeps its two steps
+                const double zeta = (be - al) * rcp_1(2.0 * ga);
+                const double zz = fma(zeta, zeta, 1.0);
+                const double tt = rcp_1(fabs(zeta) + zz * rsqrt_1(zz));
                 const double t = (zeta >= 0.0) ? tt : -tt;
                 const double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
 #pragma unroll
@@ -222,19 +236,6 @@ __device__ void jacobi_svd(double *A, double *V, int n, int ld, int lane, int &n
     else if (L == 8 && rpl <= 4) jacobi_svd_t<4, 8, NW>(A, V, n, ld, lane, n_sweeps, scratch);
     else if (L == 4 && rpl <= 8) jacobi_svd_t<8, 4, NW>(A, V, n, ld, lane, n_sweeps, scratch);
     else jacobi_svd_wide<NW>(A, V, n, ld, lane, L, n_sweeps, scratch);
-}
-
-// Two waves, n <= 32: at least 8 lanes per column pair, at most 4 rows per lane -- the light instantiations only
-// (the register-state kernel must stay under 168 VGPRs for 3 waves per SIMD).
-__device__ void jacobi_svd_small2(double *A, double *V, int n, int ld, int lane, int &n_sweeps, double *scratch) {
-    const int npairs = n >> 1;
-    int L = 1;
-    while ((L << 1) * npairs <= 128 && L < 32) L <<= 1;
-    const int rpl = (n + L - 1) / L;
-    if (L == 32) jacobi_svd_t<1, 32, 2>(A, V, n, ld, lane, n_sweeps, scratch);
-    else if (L == 16) jacobi_svd_t<1, 16, 2>(A, V, n, ld, lane, n_sweeps, scratch);
-    else if (rpl <= 2) jacobi_svd_t<2, 8, 2>(A, V, n, ld, lane, n_sweeps, scratch);
-    else jacobi_svd_t<4, 8, 2>(A, V, n, ld, lane, n_sweeps, scratch);
 }
 
 }  // namespace
@@ -474,60 +475,162 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Register-state form for up to 32 detections (two waves per frame).  X, Y and W of matchSVT are element-wise state:
-// thread t owns the pairs (i <= l) number t, t + 128, ... (at most 5 of the 528) and keeps x = X[i][l] = X[l][i],
-// y_il, y_li and w for them in registers.  LDS then holds only A, V and B = X + Y/mu (the SVT input, rebuilt by the
-// owners after every update): 3 matrices instead of 4 leave room for 6 frames per CU instead of 4, i.e. 3 waves per
-// SIMD for the latency-bound Jacobi chain.  Arithmetic, order of operations and results are those of
-// p2s_assoc_kernel.
-template <typename T>
-__global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs a) {
-    constexpr int NW = 2, NT = 128, KP = 5;
+// Symmetric form for up to 32 detections: ONE wave per frame, no workgroup barrier anywhere.
+//
+// The SVT input B = X + Y/mu of matchSVT (:480) is symmetric to rounding (X is symmetrised at :496, Y only ever
+// receives X - Q with Q = U diag(.) Vt of a symmetric matrix), so its SVD is its eigendecomposition with the signs
+// moved into U.  With a shift c >= ||B||_F the matrix M = B + cI is positive definite: the one-sided Jacobi iteration
+// on M then needs NO accumulated V -- once the columns of G = M V are orthogonal, v_j = g_j / |g_j| and the
+// eigenvalue of B is lambda_j = |g_j| - c -- and Q = sum_j sgn(lambda_j) max(|lambda_j| - t, 0) v_j v_j^T.  That halves
+// the LDS traffic and the rotation work of a step and frees one LDS matrix.  What else is different from
+// p2s_assoc_kernel:
+//   * the squared column norms travel with the columns (alpha' = alpha - t gamma, beta' = beta + t gamma; stored in
+//     the padding element of each column, refreshed from the data in the first step of every sweep), so a step
+//     reduces one dot product over the L lanes of a column pair instead of three;
+//   * a step is issue bound, not latency bound (every fp64 or 32-bit VALU instruction costs a wave ~4 cycles of its
+//     SIMD), so the frame gets one wave (L = 4 lanes x 8 rows per column pair at 32 detections: the rotation's ~30
+//     scalar-like instructions are issued once per frame instead of once per wave of the frame) and the CU hides the
+//     chain latency with 12 frames = 3 waves per SIMD: G (n x (n+1)), the packed triangle of B and the view list are
+//     12 800 B of LDS, 10 allocation granules;
+//   * X, Y and W of matchSVT are symmetric element-wise state in the registers of the lane that owns the pair
+//     (lane + 64 k is the pair's index in the packed triangle), 9 pairs per lane;
+//   * the next pass starts from V of this one (G <- (B' + c'I) V: B changes little between ADMM passes).
+// The rotation, thresholds, update arithmetic and stopping rules are those of p2s_assoc_kernel; results differ from
+// it by rounding (tests/test_assoc_gpu.py runs both on the same frames).
+template <int L>
+__device__ __forceinline__ void group_sum1(double &c) {
+    if constexpr (L >= 2) c += dpp_move<0xB1>(c);
+    if constexpr (L >= 4) c += dpp_move<0x4E>(c);
+    if constexpr (L >= 8) c += dpp_move<0x141>(c);
+    if constexpr (L >= 16) c += dpp_move<0x140>(c);
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// One round-robin step on the column pairs (p, q) of the groups of L lanes.  FRESH: the squared norms come from the
+// data (first step of a sweep: every column is in exactly one pair), otherwise from the columns' padding elements.
+// Returns whether this lane's pair was further than the sweep tolerance from orthogonal.
+template <int L, int RPL, bool FRESH>
+__device__ __forceinline__ bool sym_step(double *G, int p, int q, int r0, int sub) {
+    constexpr int R = L * RPL, LD = R + 1;
+    double *ap = G + p * LD, *aq = G + q * LD;
+    double x[RPL], y[RPL];
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) { x[i] = ap[r0 + i]; y[i] = aq[r0 + i]; }
+    double al, be, ga = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) ga = fma(x[i], y[i], ga);
+    if constexpr (FRESH) {
+        al = 0.0; be = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) { al = fma(x[i], x[i], al); be = fma(y[i], y[i], be); }
+        group_sum3<L>(al, be, ga);
+    } else {
+        al = ap[R]; be = aq[R];
+        group_sum1<L>(ga);
+    }
+    const double ab = al * be, g2 = ga * ga;
+    const bool rot = g2 > 1e-30 * ab;                   // false for the all-zero padding columns and for NaN
+    if (FRESH || __any(rot)) {
+        // Rutishauser's formulas.  The angle only has to annihilate the off-diagonal to working precision (one Newton
+        // step on the hardware seeds: 4e-15, exp/seed_precision.hip); the orthogonality of the rotation hangs on c.
+        const double zeta = (be - al) * rcp_1(2.0 * ga);
+        const double zz = fma(zeta, zeta, 1.0);
+        const double tt = rcp_1(fabs(zeta) + zz * rsqrt_1(zz));
+        const double t = rot ? __builtin_copysign(tt, zeta) : 0.0;
+        const double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            ap[r0 + i] = fma(c, x[i], -(sn * y[i]));
+            aq[r0 + i] = fma(sn, x[i], c * y[i]);
+        }
+        if (sub == 0) {
+            const double d = t * ga;
+            ap[R] = al - d; aq[R] = be + d;
+        }
+    }
+    return rot && (g2 > 1e-16 * ab);                    // a pair orthogonal to 1e-8 is orthogonal to rounding after its rotation
+}
+
+// One-sided Jacobi iteration on the n x n matrix in G (column-major, leading dimension R + 1, rows and columns
+// n .. R-1 zero) until a whole sweep found every pair orthogonal to 1e-8.  Groups without a pair (n < R) spin on two
+// of the zero columns.  Returns the number of sweeps.
+template <int L, int RPL>
+__device__ int jacobi_sym(double *G, int n, int lane) {
+    const int m = n - 1, k = lane / L, sub = lane % L, r0 = sub * RPL;
+    const bool on = k < (n >> 1);
+    int sweeps = 0;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        ++sweeps;
+        // round-robin (circle method), step 0: (m, 0) for group 0, (k, m - k) for the others; every later step moves
+        // both columns one place round the circle of m
+        int p = on ? (k == 0 ? m : k) : 2 * k, q = on ? (k == 0 ? 0 : m - k) : 2 * k + 1;
+        bool far = sym_step<L, RPL, true>(G, p, q, r0, sub);
+        lds_fence<1>();
+        for (int s = 1; s < m; ++s) {
+            if (on) {
+                if (k == 0) q = s;
+                else { p = (p + 1 == m) ? 0 : p + 1; q = (q + 1 == m) ? 0 : q + 1; }
+            }
+            far = sym_step<L, RPL, false>(G, p, q, r0, sub) || far;
+            lds_fence<1>();
+        }
+        if (!__any(far)) break;
+    }
+    return sweeps;
+}
+
+template <typename T, int L, int RPL>
+__global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a) {
+    constexpr int R = L * RPL;                      // padded order: 32 (L = 4, RPL = 8) or 16 (L = 8, RPL = 2)
+    constexpr int LD = R + 1;
+    constexpr int NPK = R * (R + 1) / 2;            // packed triangle of B
+    constexpr int KP = (NPK + 63) / 64;             // pairs per lane
+    constexpr int PARTS = 64 / R, CPL = R / PARTS;  // warm-start product: lane = (row, part), CPL columns per lane
     extern __shared__ __align__(16) unsigned char smem[];
-    const int n_max = a.Nmax;                       // even, <= 32
-    const int mat = n_max * (n_max + 1);
-    double *A = reinterpret_cast<double *>(smem);
-    double *V = A + mat;
-    double *B = V + mat;
-    double *wts = B + mat;
-    double *scratch = wts + n_max;
-    int *view = reinterpret_cast<int *>(scratch + 4);
-    double *rays = A;                               // [person][joint in chunk][7], aliases A, V, B
+    double *G = reinterpret_cast<double *>(smem);   // [R][LD]; element R of a column: its squared norm, later its weight
+    double *Bp = G + R * LD;                        // B[i][l] = B[l][i] at l (l + 1) / 2 + i, i <= l
+    int *view = reinterpret_cast<int *>(Bp + NPK);
+    double *rays = G;                               // [person][joint in chunk][7], aliases G and Bp
     const int lane = threadIdx.x;
     const int64_t f = blockIdx.x;
-    const int C = a.C, Kj = a.Kj;
+    const int C = a.C, Kj = a.Kj, n_max = a.Nmax;   // n_max even, <= R
     double *out = a.affinity + f * (int64_t)n_max * n_max;
 
     int N = 0;
     for (int c = 0; c < C; ++c) {
         const int pc = a.n_persons[f * C + c];
-        for (int i = lane; i < pc; i += NT)
+        for (int i = lane; i < pc; i += 64)
             if (N + i < n_max) view[N + i] = c;
         N += pc;
     }
     N = min(N, n_max);
     const int n = max(2, (N + 1) & ~1);
-    const int ld = n + 1;
-    for (int i = N + lane; i < n; i += NT) view[i] = -1 - i;
-    for (int i = lane; i < n_max * n_max; i += NT) out[i] = 0.0;
-    lds_fence<NW>();
+    for (int i = N + lane; i < R; i += 64) view[i] = -1 - i;
+    for (int i = lane; i < n_max * n_max; i += 64) out[i] = 0.0;
+    lds_fence<1>();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the zeros land before the result of another lane
     if (N == 0) return;
 
-    // the pairs this thread owns
+    // the pairs this lane owns
     int pi[KP], pl[KP];
     bool own[KP];                                   // a pair of real detections (not the zero padding)
-    double x[KP], yil[KP], yli[KP], w[KP], num[KP], den[KP];
-    const int n_all = n * (n + 1) / 2;
+    double x[KP], y[KP], w[KP], num[KP], den[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        const int pr = lane + k * NT;
+        const int pr = lane + k * 64;
         int l = (int)((sqrt(1.0 + 8.0 * (double)pr) - 1.0) * 0.5);
         while (l * (l + 1) / 2 > pr) --l;
         while ((l + 1) * (l + 2) / 2 <= pr) ++l;
         pl[k] = l;
         pi[k] = pr - l * (l + 1) / 2;               // i <= l
-        own[k] = pr < n_all && l < N;
-        x[k] = 0.0; yil[k] = 0.0; yli[k] = 0.0; w[k] = 0.0; num[k] = 0.0; den[k] = 0.0;
+        own[k] = l < N;
+        if (!own[k]) { pl[k] = 0; pi[k] = 0; }      // harmless addresses for the loads of the product below
+        x[k] = 0.0; y[k] = 0.0; w[k] = 0.0; num[k] = 0.0; den[k] = 0.0;
     }
 
     const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
@@ -537,11 +640,11 @@ __global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs 
     if (trace) t_start = __builtin_amdgcn_s_memtime();
 
     // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
-    int Kc = (3 * mat) / (7 * N);
+    int Kc = (R * LD + NPK) / (7 * N);
     Kc = max(1, min(Kc, Kj));
     for (int j0 = 0; j0 < Kj; j0 += Kc) {
         const int kc = min(Kc, Kj - j0);
-        for (int it = lane; it < N * kc; it += NT) {          // compute_rays (:293-314)
+        for (int it = lane; it < N * kc; it += 64) {          // compute_rays (:293-314)
             const int i = it / kc, j = it - i * kc;
             const P2sCam &cam = a.cams[view[i]];
             const T *o = kp + ((int64_t)i * Kj + j0 + j) * 3;
@@ -564,7 +667,7 @@ __global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs 
             double *r = rays + ((size_t)i * kc + j) * 7;
             r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1; r[5] = m2; r[6] = lk;
         }
-        lds_fence<NW>();
+        lds_fence<1>();
 #pragma unroll
         for (int k = 0; k < KP; ++k) {                        // compute_affinity (:383-394) for the owned pairs
             if (!own[k] || pi[k] == pl[k] || view[pi[k]] == view[pl[k]]) continue;
@@ -581,122 +684,133 @@ __global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs 
             num[k] += nm;
             den[k] += dn;
         }
-        lds_fence<NW>();
+        lds_fence<1>();
     }
     // distance -> affinity (:397-406), circular constraint (:794-795), matchSVT initialisation (:467-475)
     const double thr = a.recon_thr;
-    for (int i = lane; i < n * ld; i += NT) B[i] = 0.0;
-    lds_fence<NW>();
+    for (int i = lane; i < R * LD + NPK; i += 64) G[i] = 0.0;          // G and Bp
+    lds_fence<1>();
+    double sx = 0.0, sy = 0.0;                                         // ||X||_F^2, ||Y||_F^2 over the full matrices
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        if (lane + k * NT >= n_all) continue;
+        if (!own[k]) continue;
         const int i = pi[k], l = pl[k];
         if (i == l) { x[k] = 0.0; w[k] = a.w_sparse; continue; }
         double aff = 0.0;
-        if (i < N && l < N && view[i] != view[l]) {
+        if (view[i] != view[l]) {
             double d = num[k] / (1e-5 + den[k]);
             d = d > thr ? thr : d;
             aff = 1.0 - d / thr;
         }
         x[k] = aff;
         w[k] = a.w_sparse - aff;
-        B[i * ld + l] = aff; B[l * ld + i] = aff;             // B = X + Y/mu with Y = 0
+        Bp[lane + k * 64] = aff;                                       // B = X + Y/mu with Y = 0
+        sx = fma(2.0 * aff, aff, sx);
     }
-    lds_fence<NW>();
+    sx = wave_sum_dpp(sx);
+    lds_fence<1>();
     if (trace) t_aff = __builtin_amdgcn_s_memtime() - t_start;
 
     // ---- matchSVT (:477-505) --------------------------------------------------------------
-    double mu = 64.0;
+    double mu = 64.0, inv_mu = 1.0 / 64.0;                             // mu stays a power of two: x / mu == x * inv_mu
+    // the shift: c >= ||X||_F + ||Y||_F / mu >= ||B||_2, with a margin that keeps M = B + cI well conditioned
+    double shift = fma(1.0625, sqrt(sx), 0.5);
     for (int iter = 0; iter < a.max_iter; ++iter) {
         uint64_t tt0 = 0;
         if (trace) { tt0 = __builtin_amdgcn_s_memtime(); ++n_iter; }
-        if (iter == 0) {
-            for (int i = lane; i < n * n; i += NT) {
-                const int r = i / n, c = i - r * n;
-                A[c * ld + r] = B[r * ld + c];
-                V[c * ld + r] = (r == c) ? 1.0 : 0.0;
-            }
-        } else {                                              // warm start: A = B . V_prev
-            const int lpr = max(1, NT / n);
-            const int row = lane % n, part = lane / n;
-            const int cpl = (n + lpr - 1) / lpr;
-            const bool on = part < lpr;
-            {                                                 // n <= 32 and 128 threads: at most 8 columns per thread
-                double acc[8];
+        {
+            const int row = lane % R, part = lane / R, j0 = part * CPL;
+            double acc[CPL];
+            if (iter == 0) {                                  // V = I: G = M
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) acc[jj] = 0.0;
-                const int j0 = part * cpl;
-                const int nj = on ? max(0, min(min(8, cpl), n - j0)) : 0;
-                for (int kk = 0; kk < n; ++kk) {
-                    const double bk = B[row * ld + kk];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj)
-                        if (jj < nj) acc[jj] = fma(bk, V[(j0 + jj) * ld + kk], acc[jj]);
+                for (int jj = 0; jj < CPL; ++jj) {
+                    const int j = j0 + jj, lo = min(row, j), hi = max(row, j);
+                    acc[jj] = Bp[hi * (hi + 1) / 2 + lo] + ((row == j && row < n) ? shift : 0.0);
                 }
+            } else {                                          // warm start: G <- M V, V = the normalised columns of G
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj)
-                    if (jj < nj) A[(j0 + jj) * ld + row] = acc[jj];
+                for (int jj = 0; jj < CPL; ++jj) acc[jj] = shift * G[(j0 + jj) * LD + row];
+                int idx = row * (row + 1) / 2;
+                for (int kk = 0; kk < n; ++kk) {
+                    const double bk = Bp[idx];                // B[row][kk]
+                    idx += (kk < row) ? 1 : kk + 1;
+#pragma unroll
+                    for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma(bk, G[(j0 + jj) * LD + kk], acc[jj]);
+                }
+            }
+            lds_fence<1>();                                   // every lane has read V before anyone overwrites it
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) G[(j0 + jj) * LD + row] = acc[jj];
+        }
+        lds_fence<1>();
+        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_prod += t - tt0; tt0 = t; }
+        n_sweeps += jacobi_sym<L, RPL>(G, n, lane);
+        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_svd += t - tt0; tt0 = t; }
+        // singular values sigma_j = |g_j| of M, eigenvalues lambda_j = sigma_j - c of B; G <- V; the SVT weight
+        // sgn(lambda) max(|lambda| - t, 0) (:443-445 with u_j = sgn(lambda_j) v_j) goes to the column's padding element
+        const double tsv = a.w_rank / mu;
+        {
+            const int k = lane / L, sub = lane % L, r0 = sub * RPL;
+#pragma unroll
+            for (int jb = 0; jb < R; jb += 64 / L) {
+                double *col = G + (jb + k) * LD;
+                double v[RPL], s2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) { v[i] = col[r0 + i]; s2 = fma(v[i], v[i], s2); }
+                group_sum1<L>(s2);
+                const double is = (s2 > 0.0) ? p2s_rsqrt(s2) : 0.0;
+                const double lam = s2 * is - shift;
+                const double mag = fabs(lam) - tsv;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) col[r0 + i] = v[i] * is;
+                if (sub == 0) col[R] = (mag > 0.0) ? __builtin_copysign(mag, lam) : 0.0;
             }
         }
-        lds_fence<NW>();
-        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_prod += t - tt0; tt0 = t; }
-        jacobi_svd_small2(A, V, n, ld, lane, n_sweeps, scratch);
-        if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_svd += t - tt0; tt0 = t; }
-        const double tsv = a.w_rank / mu;
-        for (int j = lane; j < n; j += NT) {
-            double s2 = 0.0;
-            for (int r = 0; r < n; ++r) s2 = fma(A[j * ld + r], A[j * ld + r], s2);
-            const double sg = sqrt(s2);
-            wts[j] = (sg > tsv) ? (sg - tsv) / sg : 0.0;
+        lds_fence<1>();
+        double q[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) q[k] = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double *col = G + j * LD;
+            const double hj = col[R];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) q[k] = fma(hj * col[pi[k]], col[pl[k]], q[k]);
         }
-        lds_fence<NW>();
         double pres2 = 0.0, dres2 = 0.0;
+        sx = 0.0; sy = 0.0;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             if (!own[k]) continue;
             const int i = pi[k], l = pl[k];
-            double q_il = 0.0, q_li = 0.0;                    // SVT (:443-445): U diag(max(s-t,0)) Vt
-            for (int j = 0; j < n; ++j) {
-                const double wj = wts[j];
-                q_il = fma(wj * A[j * ld + i], V[j * ld + l], q_il);
-                q_li = fma(wj * A[j * ld + l], V[j * ld + i], q_li);
-            }
             const bool same_view = view[i] == view[l];
-            double x_il = q_il - (w[k] + yil[k]) / mu;        // :482
-            double x_li = q_li - (w[k] + yli[k]) / mu;
-            if (same_view) { x_il = 0.0; x_li = 0.0; }        // :485-487
-            if (i == l) { x_il = 1.0; x_li = 1.0; }           // :490
-            x_il = x_il < 0.0 ? 0.0 : x_il; x_il = x_il > 1.0 ? 1.0 : x_il;   // :491-492
-            x_li = x_li < 0.0 ? 0.0 : x_li; x_li = x_li > 1.0 ? 1.0 : x_li;
-            const double cc = (same_view && i != l) ? 0.0 : 1.0;              // :495
-            x_il *= cc; x_li *= cc;
-            const double sym = (x_il + x_li) / 2;             // :496
-            const double old = x[k];
-            yil[k] = yil[k] + mu * (sym - q_il);              // :497
-            pres2 += (sym - q_il) * (sym - q_il);
-            dres2 += (sym - old) * (sym - old);
-            if (i != l) {
-                yli[k] = yli[k] + mu * (sym - q_li);
-                pres2 += (sym - q_li) * (sym - q_li);
-                dres2 += (sym - old) * (sym - old);
-            }
-            x[k] = sym;
+            double xn = q[k] - (w[k] + y[k]) * inv_mu;        // :482
+            if (same_view) xn = 0.0;                          // :485-487
+            if (i == l) xn = 1.0;                             // :490
+            xn = xn < 0.0 ? 0.0 : xn; xn = xn > 1.0 ? 1.0 : xn;   // :491-492
+            // :495 multiplies the same-view entries by 0 once more; :496 (X + X.T) / 2 of a symmetric X is X
+            const double dq = xn - q[k], dx = xn - x[k];
+            const double mult = (i == l) ? 1.0 : 2.0;         // both triangles
+            y[k] = fma(mu, dq, y[k]);                         // :497
+            pres2 = fma(mult * dq, dq, pres2);
+            dres2 = fma(mult * dx, dx, dres2);
+            x[k] = xn;
+            sx = fma(mult * xn, xn, sx);
+            sy = fma(mult * y[k], y[k], sy);
         }
         if (trace) t_upd += __builtin_amdgcn_s_memtime() - tt0;
-        const double pRes = sqrt(block_sum<NW>(pres2, scratch, lane)) / (double)N;          // :500
-        const double dRes = mu * sqrt(block_sum<NW>(dres2, scratch, lane)) / (double)N;     // :501
+        pres2 = wave_sum_dpp(pres2); dres2 = wave_sum_dpp(dres2);
+        const double pRes = sqrt(pres2) / (double)N;                    // :500
+        const double dRes = mu * sqrt(dres2) / (double)N;               // :501
         if (pRes < a.tol && dRes < a.tol) break;                        // :502
-        if (pRes > 10 * dRes) mu = 2 * mu;                              // :504
-        else if (dRes > 10 * pRes) mu = mu / 2;                         // :505
+        if (pRes > 10 * dRes) { mu = 2 * mu; inv_mu = 0.5 * inv_mu; }   // :504
+        else if (dRes > 10 * pRes) { mu = mu / 2; inv_mu = 2 * inv_mu; }   // :505
+        sx = wave_sum_dpp(sx); sy = wave_sum_dpp(sy);
+        shift = fma(1.0625, sqrt(sx) + sqrt(sy) * inv_mu, 0.5);
         // the next pass's SVT input, B = X + Y/mu (:480), from the owners
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            if (!own[k]) continue;
-            const int i = pi[k], l = pl[k];
-            B[i * ld + l] = x[k] + yil[k] * 1.0 / mu;
-            if (i != l) B[l * ld + i] = x[k] + yli[k] * 1.0 / mu;
-        }
-        lds_fence<NW>();
+        for (int k = 0; k < KP; ++k)
+            if (own[k]) Bp[lane + k * 64] = x[k] + y[k] * inv_mu;
+        lds_fence<1>();
     }
     // ---- min_affinity cut (:800) and store --------------------------------------------------------
 #pragma unroll
@@ -708,7 +822,7 @@ __global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs 
         out[l * n_max + i] = v;
     }
     if (trace) {
-        lds_fence<NW>();
+        lds_fence<1>();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (lane == 0) {
             out[0] = (double)(__builtin_amdgcn_s_memtime() - t_start); out[1] = (double)t_aff; out[2] = (double)t_prod;
@@ -718,29 +832,27 @@ __global__ void __launch_bounds__(128, 3) p2s_assoc_kernel_r(const P2sAssocArgs 
 }
 
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
+    if (a.Nmax <= 32 && a.form != P2S_ASSOC_FORM_GENERAL) {           // symmetric form, one wave per frame
+        auto go_s = [&](auto kern, int R) -> hipError_t {
+            const size_t lds = (size_t)(R * (R + 1) + R * (R + 1) / 2) * sizeof(double) + (size_t)R * sizeof(int);
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return err;
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
+            return hipGetLastError();
+        };
+        if (a.Nmax <= 16) return dtype == P2S_F32 ? go_s(&p2s_assoc_kernel_s<float, 8, 2>, 16) : go_s(&p2s_assoc_kernel_s<double, 8, 2>, 16);
+        return dtype == P2S_F32 ? go_s(&p2s_assoc_kernel_s<float, 4, 8>, 32) : go_s(&p2s_assoc_kernel_s<double, 4, 8>, 32);
+    }
+    // general form: no symmetry assumed, V accumulated, four LDS matrices; two waves per frame from 18 detections up
+    // (the Jacobi step is a chain of dependent operations and ~34 KB of LDS per frame leave one wave per SIMD otherwise)
     const size_t lds = (size_t)(4 * a.Nmax * (a.Nmax + 1) + a.Nmax + 4) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
-    // two waves per frame from 18 detections up: the Jacobi step is a chain of dependent operations, and with
-    // ~34 KB of LDS per frame only 4 frames fit a CU -- a second wave per frame gives every SIMD two waves to
-    // interleave and halves the rows a lane rotates
-    const bool two = a.Nmax > 16 && !getenv("P2S_ASSOC_ONE_WAVE");
-    hipError_t e;
+    const bool two = a.Nmax > 16;
     auto go = [&](auto kern, int threads) -> hipError_t {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return err;
         hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(threads), lds, s, a);
         return hipGetLastError();
     };
-    if (two && a.Nmax <= 32 && !getenv("P2S_ASSOC_LDS_STATE")) {      // element-wise state in registers: 3 matrices in LDS
-        const size_t lds3 = (size_t)(3 * a.Nmax * (a.Nmax + 1) + a.Nmax + 4) * sizeof(double) + (size_t)a.Nmax * sizeof(int) + 16;
-        auto go3 = [&](auto kern) -> hipError_t {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (err != hipSuccess) return err;
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(128), lds3, s, a);
-            return hipGetLastError();
-        };
-        return dtype == P2S_F32 ? go3(&p2s_assoc_kernel_r<float>) : go3(&p2s_assoc_kernel_r<double>);
-    }
-    if (dtype == P2S_F32) e = two ? go(&p2s_assoc_kernel<float, 2>, 128) : go(&p2s_assoc_kernel<float, 1>, 64);
-    else e = two ? go(&p2s_assoc_kernel<double, 2>, 128) : go(&p2s_assoc_kernel<double, 1>, 64);
-    return e;
+    if (dtype == P2S_F32) return two ? go(&p2s_assoc_kernel<float, 2>, 128) : go(&p2s_assoc_kernel<float, 1>, 64);
+    return two ? go(&p2s_assoc_kernel<double, 2>, 128) : go(&p2s_assoc_kernel<double, 1>, 64);
 }

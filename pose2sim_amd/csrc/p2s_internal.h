@@ -118,6 +118,7 @@ struct P2sAssocArgs {
     int64_t n_frames;
     int32_t C, Kj, Nmax, max_iter;
     int32_t debug_mode;         // diagnostics only: 7 = per-frame phase timeline instead of the result (exp/assoc_trace.py)
+    int32_t form;               // P2S_ASSOC_FORM_* (p2s_set_tuning: tests run both kernels on the same frames)
     double recon_thr, min_affinity, w_rank, tol, w_sparse;
 };
 

@@ -89,7 +89,9 @@ class Engine:
 
     # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
     TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS, TUNE_DEEP_MIN_SUBSETS = 1, 2, 3, 4, 5, 6, 7
+    TUNE_ASSOC_FORM = 8
     TRI_PATH_AUTO, TRI_PATH_WORKLIST = 0, 1
+    ASSOC_FORM_AUTO, ASSOC_FORM_GENERAL = 0, 1
 
     def tri_stats(self, reset=False):
         """Counters of this engine's triangulation calls: units that entered the camera-subset search, subsets

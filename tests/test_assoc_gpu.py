@@ -18,12 +18,16 @@ from test_oracle_golden import _assoc_groups, assoc_frames_of
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module')
-def engine():
+@pytest.fixture(scope='module', params=['auto', 'general'])
+def engine(request):
+    """'auto': frames of up to 32 detections take the symmetric one-wave kernel; 'general': the kernel that assumes
+    no symmetry and accumulates V at every size -- two implementations of matchSVT against the same references."""
     import __graft_entry__ as entry
     entry.build_hip()
     from pose2sim_amd.engine import Engine
     eng = Engine(0)
+    if request.param == 'general':
+        eng.set_tuning(Engine.TUNE_ASSOC_FORM, Engine.ASSOC_FORM_GENERAL)
     yield eng
     eng.close()
 
