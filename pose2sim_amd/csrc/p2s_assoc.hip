@@ -511,88 +511,104 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return v;
 }
 
-// One round-robin step on the column pairs (p, q) of the groups of L lanes.  FRESH: the squared norms come from the
-// data (first step of a sweep: every column is in exactly one pair), otherwise from the columns' padding elements.
-// Returns whether this lane's pair was further than the sweep tolerance from orthogonal.
+// One step of the odd-even ordering for the group's pair (incoming column = LDS slot `col`, kept column = registers):
+// rotate, then the two change places -- the rotated kept column goes to the slot, the rotated incoming one stays in
+// registers.  FRESH: the squared norms come from the data (first step of a sweep: every column is in a pair),
+// otherwise the incoming one from the slot's padding element and the kept one from a register.  Straight-line code:
+// a group without a pair in this step (act false) runs the same instructions on a slot nobody else uses, with the
+// "rotation" (c, s) = (0, -1) that leaves its kept column where it is.  Returns whether this lane's pair was further
+// than the sweep tolerance from orthogonal.
 template <int L, int RPL, bool FRESH>
-__device__ __forceinline__ bool sym_step(double *G, int p, int q, int r0, int sub) {
-    constexpr int R = L * RPL, LD = R + 1;
-    double *ap = G + p * LD, *aq = G + q * LD;
-    double x[RPL], y[RPL];
+__device__ __forceinline__ bool oe_step(double *col, bool act, int sub, double (&kept)[RPL], double &bk) {
+    constexpr int R = L * RPL;
+    double *mine = col + sub;                            // rows sub, sub + L, ...: see the bank arithmetic at the kernel
+    double x[RPL];
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) { x[i] = ap[r0 + i]; y[i] = aq[r0 + i]; }
-    double al, be, ga = 0.0;
+    for (int i = 0; i < RPL; ++i) x[i] = mine[L * i];
+    double al, ga = 0.0;
 #pragma unroll
-    for (int i = 0; i < RPL; ++i) ga = fma(x[i], y[i], ga);
+    for (int i = 0; i < RPL; ++i) ga = fma(x[i], kept[i], ga);
     if constexpr (FRESH) {
-        al = 0.0; be = 0.0;
+        al = 0.0; bk = 0.0;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) { al = fma(x[i], x[i], al); be = fma(y[i], y[i], be); }
-        group_sum3<L>(al, be, ga);
+        for (int i = 0; i < RPL; ++i) { al = fma(x[i], x[i], al); bk = fma(kept[i], kept[i], bk); }
+        group_sum3<L>(al, bk, ga);
     } else {
-        al = ap[R]; be = aq[R];
+        al = col[R];
         group_sum1<L>(ga);
     }
-    const double ab = al * be, g2 = ga * ga;
-    const bool rot = g2 > 1e-30 * ab;                   // false for the all-zero padding columns and for NaN
-    if (FRESH || __any(rot)) {
-        // Rutishauser's formulas.  The angle only has to annihilate the off-diagonal to working precision (one Newton
-        // step on the hardware seeds: 4e-15, exp/seed_precision.hip); the orthogonality of the rotation hangs on c.
-        const double zeta = (be - al) * rcp_1(2.0 * ga);
-        const double zz = fma(zeta, zeta, 1.0);
-        const double tt = rcp_1(fabs(zeta) + zz * rsqrt_1(zz));
-        const double t = rot ? __builtin_copysign(tt, zeta) : 0.0;
-        const double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
+    const double ab = al * bk, g2 = ga * ga;
+    const bool rot = act && (g2 > 1e-30 * ab);           // false for the all-zero padding columns and for NaN
+    // Rutishauser's formulas.  The angle only has to annihilate the off-diagonal to working precision (one Newton
+    // step on the hardware seeds: 4e-15, exp/seed_precision.hip); the orthogonality of the rotation hangs on c.
+    const double zeta = (bk - al) * rcp_1(2.0 * ga);
+    const double zz = fma(zeta, zeta, 1.0);
+    const double tt = rcp_1(fabs(zeta) + zz * rsqrt_1(zz));
+    const double t = rot ? __builtin_copysign(tt, zeta) : 0.0;
+    double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
+    const double d = t * ga;
+    c = act ? c : 0.0; sn = act ? sn : -1.0;
 #pragma unroll
-        for (int i = 0; i < RPL; ++i) {
-            ap[r0 + i] = fma(c, x[i], -(sn * y[i]));
-            aq[r0 + i] = fma(sn, x[i], c * y[i]);
-        }
-        if (sub == 0) {
-            const double d = t * ga;
-            ap[R] = al - d; aq[R] = be + d;
-        }
+    for (int i = 0; i < RPL; ++i) {
+        mine[L * i] = fma(sn, x[i], c * kept[i]);
+        kept[i] = fma(c, x[i], -(sn * kept[i]));
     }
-    return rot && (g2 > 1e-16 * ab);                    // a pair orthogonal to 1e-8 is orthogonal to rounding after its rotation
+    col[R] = bk + d;                                     // the L lanes of the group store the same value
+    bk = act ? al - d : bk;
+    return rot && (g2 > 1e-16 * ab);                     // a pair orthogonal to 1e-8 is orthogonal to rounding after its rotation
 }
 
-// One-sided Jacobi iteration on the n x n matrix in G (column-major, leading dimension R + 1, rows and columns
-// n .. R-1 zero) until a whole sweep found every pair orthogonal to 1e-8.  Groups without a pair (n < R) spin on two
-// of the zero columns.  Returns the number of sweeps.
+// One-sided Jacobi iteration on the n x n matrix in G (column-major, leading dimension LD, rows and columns n .. R-1
+// zero) until a whole sweep found every pair orthogonal to 1e-8.  Odd-even ordering: the columns stand in a line,
+// even steps pair the positions (2k, 2k+1), odd steps (2k+1, 2k+2), and a pair changes places after its rotation, so
+// that after n steps every two columns have met once (the line is then reversed).  Group k of L lanes keeps the column
+// at position 2k+1 in registers and only ever exchanges the other one with the LDS slots 2k (even steps) and 2k+2
+// (odd steps): one column read and one written per step instead of two and two -- the stores are what the CU's LDS
+// path runs out of first (13 cycles per 1 KiB store instruction, MI355X_MICROARCH.md LDS).  The odd slots are not
+// used while the iteration runs (they are rewritten at the end): a group without a pair plays with its own.
+// Returns the sweeps.
 template <int L, int RPL>
-__device__ int jacobi_sym(double *G, int n, int lane) {
-    const int m = n - 1, k = lane / L, sub = lane % L, r0 = sub * RPL;
-    const bool on = k < (n >> 1);
+__device__ __forceinline__ int jacobi_oe(double *G, int n, int lane) {
+    constexpr int R = L * RPL, LD = R + L / 2;
+    const int k = lane / L, sub = lane % L, half = n >> 1;
+    double *odd = G + (2 * k + 1) * LD;
+    const bool actA = k < half, actB = k < half - 1;
+    double *colA = actA ? odd - LD : odd, *colB = actB ? odd + LD : odd;
+    double kept[RPL], bk = 0.0;
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) kept[i] = odd[sub + L * i];
     int sweeps = 0;
     for (int sweep = 0; sweep < 40; ++sweep) {
         ++sweeps;
-        // round-robin (circle method), step 0: (m, 0) for group 0, (k, m - k) for the others; every later step moves
-        // both columns one place round the circle of m
-        int p = on ? (k == 0 ? m : k) : 2 * k, q = on ? (k == 0 ? 0 : m - k) : 2 * k + 1;
-        bool far = sym_step<L, RPL, true>(G, p, q, r0, sub);
+        bool far = oe_step<L, RPL, true>(colA, actA, sub, kept, bk);
         lds_fence<1>();
-        for (int s = 1; s < m; ++s) {
-            if (on) {
-                if (k == 0) q = s;
-                else { p = (p + 1 == m) ? 0 : p + 1; q = (q + 1 == m) ? 0 : q + 1; }
-            }
-            far = sym_step<L, RPL, false>(G, p, q, r0, sub) || far;
+        for (int j = 1; j < half; ++j) {
+            far = oe_step<L, RPL, false>(colB, actB, sub, kept, bk) || far;
+            lds_fence<1>();
+            far = oe_step<L, RPL, false>(colA, actA, sub, kept, bk) || far;
             lds_fence<1>();
         }
+        far = oe_step<L, RPL, false>(colB, actB, sub, kept, bk) || far;
+        lds_fence<1>();
         if (!__any(far)) break;
     }
+#pragma unroll
+    for (int i = 0; i < RPL; ++i) odd[sub + L * i] = kept[i];
     return sweeps;
 }
 
 template <typename T, int L, int RPL>
 __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a) {
     constexpr int R = L * RPL;                      // padded order: 32 (L = 4, RPL = 8) or 16 (L = 8, RPL = 2)
-    constexpr int LD = R + 1;
+    // Lane (k, sub) of the Jacobi steps works on rows sub, sub + L, ... of the even columns 2k and 2k + 2.  An 8-byte
+    // LDS read serves 32 lanes at a time from 32 double-wide banks and a store 16 lanes from 16: with 2 LD = L (mod 32)
+    // the 32 / L groups of a half wave start L banks apart and the L lanes of a group fill the gap -- no conflicts.
+    constexpr int LD = R + L / 2;
     constexpr int NPK = R * (R + 1) / 2;            // packed triangle of B
     constexpr int KP = (NPK + 63) / 64;             // pairs per lane
     constexpr int PARTS = 64 / R, CPL = R / PARTS;  // warm-start product: lane = (row, part), CPL columns per lane
     extern __shared__ __align__(16) unsigned char smem[];
-    double *G = reinterpret_cast<double *>(smem);   // [R][LD]; element R of a column: its squared norm, later its weight
+    double *G = reinterpret_cast<double *>(smem);   // [R][LD]; element R of a column: its squared norm, later its SVT weight
     double *Bp = G + R * LD;                        // B[i][l] = B[l][i] at l (l + 1) / 2 + i, i <= l
     int *view = reinterpret_cast<int *>(Bp + NPK);
     double *rays = G;                               // [person][joint in chunk][7], aliases G and Bp
@@ -744,25 +760,25 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         }
         lds_fence<1>();
         if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_prod += t - tt0; tt0 = t; }
-        n_sweeps += jacobi_sym<L, RPL>(G, n, lane);
+        n_sweeps += jacobi_oe<L, RPL>(G, n, lane);
         if (trace) { const uint64_t t = __builtin_amdgcn_s_memtime(); t_svd += t - tt0; tt0 = t; }
         // singular values sigma_j = |g_j| of M, eigenvalues lambda_j = sigma_j - c of B; G <- V; the SVT weight
         // sgn(lambda) max(|lambda| - t, 0) (:443-445 with u_j = sgn(lambda_j) v_j) goes to the column's padding element
         const double tsv = a.w_rank / mu;
         {
-            const int k = lane / L, sub = lane % L, r0 = sub * RPL;
+            const int k = lane / L, sub = lane % L;
 #pragma unroll
             for (int jb = 0; jb < R; jb += 64 / L) {
                 double *col = G + (jb + k) * LD;
                 double v[RPL], s2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) { v[i] = col[r0 + i]; s2 = fma(v[i], v[i], s2); }
+                for (int i = 0; i < RPL; ++i) { v[i] = col[sub + L * i]; s2 = fma(v[i], v[i], s2); }
                 group_sum1<L>(s2);
                 const double is = (s2 > 0.0) ? p2s_rsqrt(s2) : 0.0;
                 const double lam = s2 * is - shift;
                 const double mag = fabs(lam) - tsv;
 #pragma unroll
-                for (int i = 0; i < RPL; ++i) col[r0 + i] = v[i] * is;
+                for (int i = 0; i < RPL; ++i) col[sub + L * i] = v[i] * is;
                 if (sub == 0) col[R] = (mag > 0.0) ? __builtin_copysign(mag, lam) : 0.0;
             }
         }
@@ -834,7 +850,8 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
 hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
     if (a.Nmax <= 32 && a.form != P2S_ASSOC_FORM_GENERAL) {           // symmetric form, one wave per frame
         auto go_s = [&](auto kern, int R) -> hipError_t {
-            const size_t lds = (size_t)(R * (R + 1) + R * (R + 1) / 2) * sizeof(double) + (size_t)R * sizeof(int);
+            const int LD = R + (R == 32 ? 2 : 4);                 // R + L / 2, as in the kernel
+            const size_t lds = (size_t)(R * LD + R * (R + 1) / 2) * sizeof(double) + (size_t)R * sizeof(int);
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (err != hipSuccess) return err;
             hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
