@@ -187,6 +187,13 @@ int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, cons
  * back as not triangulated where the reference would have gone on for hours -- callers report the count). */
 int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 
+/* Counters of the multi-person association calls of this context since creation (or the last reset), after
+ * synchronising its stream: out[0] frames with at least one detection, out[1] ADMM passes of matchSVT
+ * (personAssociation.py:477-505), out[2] Jacobi sweeps of their singular value decompositions, out[3] fp64 operations
+ * by the kernels' own count (a multiplication or addition is 1, a fused multiply-add 2; rotations, products and
+ * updates as the kernel that ran does them -- the figure bench.py divides by the fp64 vector peak). */
+int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
+
 /* Experiments and tests only -- apart from P2S_TUNE_MAX_SUBSETS nothing here changes a result, and the library never
  * reads the environment.
  *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernel with the in-wave subset search where it

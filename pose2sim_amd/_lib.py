@@ -68,6 +68,7 @@ SIGNATURES = {
                                             C.POINTER(SingleParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     'p2s_set_tuning': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     'p2s_get_tri_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'p2s_get_assoc_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'p2s_butterworth_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'p2s_trc_metrics_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'p2s_timing_begin': (C.c_int, [C.c_void_p]),

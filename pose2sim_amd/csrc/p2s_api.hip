@@ -76,6 +76,7 @@ struct p2s_ctx {
     Scratch deep_entries, deep_ctl, deep_sched, deep_partials;   // deep levels of the search (p2s_tri_deep.hip)
     uint32_t deep_min_subsets = P2S_DEEP_MIN_SUBSETS;            // 0 = every level stays in the search kernel's wave
     unsigned long long *d_stats = nullptr;           // P2S_N_STATS counters (p2s_get_tri_stats)
+    unsigned long long *d_assoc_stats = nullptr;     // 4 counters (p2s_get_assoc_stats)
     uint16_t *d_sub_tab = nullptr;                   // camera subsets by level (fused kernel), built with the calibration
     uint32_t *d_sub_off = nullptr;
     // p2s_set_tuning: experiments and tests only, never read from the environment
@@ -210,6 +211,8 @@ int p2s_create(int device_id, p2s_ctx **out) {
     HIP_TRY(hipMemcpy(c->d_binom, b.data(), b.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void **)&c->d_stats, sizeof(unsigned long long) * P2S_STAT_SHARDS * P2S_STAT_STRIDE));
     HIP_TRY(hipMemset(c->d_stats, 0, sizeof(unsigned long long) * P2S_STAT_SHARDS * P2S_STAT_STRIDE));
+    HIP_TRY(hipMalloc((void **)&c->d_assoc_stats, sizeof(unsigned long long) * P2S_STAT_SHARDS * P2S_STAT_STRIDE));
+    HIP_TRY(hipMemset(c->d_assoc_stats, 0, sizeof(unsigned long long) * P2S_STAT_SHARDS * P2S_STAT_STRIDE));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
@@ -232,6 +235,7 @@ int p2s_destroy(p2s_ctx *ctx) {
     if (ctx->d_cams) (void)hipFree(ctx->d_cams);
     if (ctx->d_binom) (void)hipFree(ctx->d_binom);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_assoc_stats) (void)hipFree(ctx->d_assoc_stats);
     if (ctx->d_sub_tab) (void)hipFree(ctx->d_sub_tab);
     if (ctx->d_sub_off) (void)hipFree(ctx->d_sub_off);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -336,6 +340,20 @@ int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset) {
         for (int sh = 0; sh < P2S_STAT_SHARDS; ++sh) out[i] += h[(size_t)sh * P2S_STAT_STRIDE + i];
     }
     if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, h.size() * sizeof(unsigned long long)));
+    return P2S_OK;
+}
+
+int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset) {
+    if (!ctx || !out) return fail(P2S_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h((size_t)P2S_STAT_SHARDS * P2S_STAT_STRIDE);
+    HIP_TRY(hipMemcpy(h.data(), ctx->d_assoc_stats, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) {
+        out[i] = 0;
+        for (int sh = 0; sh < P2S_STAT_SHARDS; ++sh) out[i] += h[(size_t)sh * P2S_STAT_STRIDE + i];
+    }
+    if (reset) HIP_TRY(hipMemset(ctx->d_assoc_stats, 0, h.size() * sizeof(unsigned long long)));
     return P2S_OK;
 }
 
@@ -621,6 +639,7 @@ int p2s_associate_device(p2s_ctx *ctx, int64_t n_frames, int32_t n_kpts_json, in
     a.max_iter = params->max_iter;
     a.debug_mode = ctx->debug_mode;
     a.form = ctx->assoc_form;
+    a.stats = ctx->d_assoc_stats;
     a.recon_thr = params->reconstruction_error_threshold; a.min_affinity = params->min_affinity;
     a.w_rank = params->w_rank; a.tol = params->tol; a.w_sparse = params->w_sparse;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -105,6 +105,13 @@ __device__ __forceinline__ void group_sum3(double &a, double &b, double &c) {
     }
 }
 
+// p2s_get_assoc_stats: one lane per frame adds to the context's sharded counters
+__device__ __forceinline__ void assoc_count(const P2sAssocArgs &a, unsigned long long frames, unsigned long long passes,
+                                            unsigned long long sweeps, unsigned long long flops) {
+    unsigned long long *st = a.stats + (size_t)(blockIdx.x % P2S_STAT_SHARDS) * P2S_STAT_STRIDE;
+    atomicAdd(st + 0, frames); atomicAdd(st + 1, passes); atomicAdd(st + 2, sweeps); atomicAdd(st + 3, flops);
+}
+
 // round-robin (circle method) pairing: step s of n-1, pair k of n/2 -> columns (p, q), n even
 __device__ __forceinline__ void rr_pair(int n, int s, int k, int &p, int &q) {
     const int m = n - 1;
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
     const int n_pairs = N * (N - 1) / 2;
     const bool trace = P2S_DEBUG_MODE(a) == 7;
     uint64_t t_start = 0, t_aff = 0, t_prod = 0, t_svd = 0, t_upd = 0;
-    int n_sweeps = 0, n_iter = 0;
+    int n_sweeps = 0, n_iter = 0, n_iter_all = 0;
     if (trace) t_start = __builtin_amdgcn_s_memtime();
 
     // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
@@ -368,6 +375,7 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
     double mu = 64.0;
     for (int iter = 0; iter < a.max_iter; ++iter) {
         uint64_t tt0 = 0;
+        ++n_iter_all;
         if (trace) { tt0 = __builtin_amdgcn_s_memtime(); ++n_iter; }
         // SVT input B = X + Y/mu (:480), column-major for the column rotations.
         // First iteration: A = B, V = I.  Later iterations warm-start from the previous right singular
@@ -464,6 +472,16 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
         const double v = X[i * ld + l];
         out[i * n_max + l] = (v < a.min_affinity) ? 0.0 : v;
     }
+    if (a.stats && lane == 0) {
+        // fp64 operations of this frame (p2s_get_assoc_stats): a column-pair rotation is 3 dot products, 4 columns of
+        // n rows updated (A and V) and ~50 operations of rotation arithmetic; a pass also has the warm-start product,
+        // the rebuilt U diag Vt for both triangles and the element-wise update
+        const unsigned long long nn = (unsigned long long)n;
+        const unsigned long long flops = (unsigned long long)n_sweeps * (nn - 1) * (nn / 2) * (18 * nn + 50) +
+                                         (unsigned long long)n_iter_all * (2 * nn * nn * nn + 3 * nn * nn * nn + 30 * nn * nn) +
+                                         (unsigned long long)n_pairs * Kj * 17;
+        assoc_count(a, 1, (unsigned long long)n_iter_all, (unsigned long long)n_sweeps, flops);
+    }
     if (trace) {
         lds_fence<NW>();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -539,11 +557,13 @@ __device__ __forceinline__ bool oe_step(double *col, bool act, int sub, double (
     }
     const double ab = al * bk, g2 = ga * ga;
     const bool rot = act && (g2 > 1e-30 * ab);           // false for the all-zero padding columns and for NaN
-    // Rutishauser's formulas.  The angle only has to annihilate the off-diagonal to working precision (one Newton
-    // step on the hardware seeds: 4e-15, exp/seed_precision.hip); the orthogonality of the rotation hangs on c.
-    const double zeta = (bk - al) * rcp_1(2.0 * ga);
+    // Rutishauser's formulas.  The tangent comes straight from the hardware seeds of 1/x and 1/sqrt(x) (5e-8,
+    // exp/seed_precision.hip): a relative error e of the angle leaves e times the pair's cosine behind, and the sweep
+    // that ends the iteration only sees cosines under 1e-8.  The orthogonality of the rotation hangs on c, which keeps
+    // its two Newton steps.
+    const double zeta = (bk - al) * __builtin_amdgcn_rcp(2.0 * ga);
     const double zz = fma(zeta, zeta, 1.0);
-    const double tt = rcp_1(fabs(zeta) + zz * rsqrt_1(zz));
+    const double tt = __builtin_amdgcn_rcp(fma(zz, __builtin_amdgcn_rsq(zz), fabs(zeta)));
     const double t = rot ? __builtin_copysign(tt, zeta) : 0.0;
     double c = p2s_rsqrt(fma(t, t, 1.0)), sn = c * t;
     const double d = t * ga;
@@ -555,7 +575,9 @@ __device__ __forceinline__ bool oe_step(double *col, bool act, int sub, double (
     }
     col[R] = bk + d;                                     // the L lanes of the group store the same value
     bk = act ? al - d : bk;
-    return rot && (g2 > 1e-16 * ab);                     // a pair orthogonal to 1e-8 is orthogonal to rounding after its rotation
+    // a pair orthogonal to 1e-8 is orthogonal to rounding after its rotation (1e-7 here: 5 % less time and 3.6e-11
+    // instead of 1.4e-13 from the oracle on tests/sweeps/sweep_assoc.py)
+    return rot && (g2 > 1e-16 * ab);
 }
 
 // One-sided Jacobi iteration on the n x n matrix in G (column-major, leading dimension LD, rows and columns n .. R-1
@@ -648,11 +670,14 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         if (!own[k]) { pl[k] = 0; pi[k] = 0; }      // harmless addresses for the loads of the product below
         x[k] = 0.0; y[k] = 0.0; w[k] = 0.0; num[k] = 0.0; den[k] = 0.0;
     }
+    unsigned sv = 0;                                // bit k: the two detections of pair k are in the same view (or are the same)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) sv |= (view[pi[k]] == view[pl[k]]) ? (1u << k) : 0u;
 
     const T *kp = reinterpret_cast<const T *>(a.kpts) + a.offsets[f] * (int64_t)Kj * 3;
     const bool trace = P2S_DEBUG_MODE(a) == 7;
     uint64_t t_start = 0, t_aff = 0, t_prod = 0, t_svd = 0, t_upd = 0;
-    int n_sweeps = 0, n_iter = 0;
+    int n_sweeps = 0, n_iter = 0, n_iter_all = 0;
     if (trace) t_start = __builtin_amdgcn_s_memtime();
 
     // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
@@ -686,7 +711,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         lds_fence<1>();
 #pragma unroll
         for (int k = 0; k < KP; ++k) {                        // compute_affinity (:383-394) for the owned pairs
-            if (!own[k] || pi[k] == pl[k] || view[pi[k]] == view[pl[k]]) continue;
+            if (!own[k] || ((sv >> k) & 1)) continue;
             const double *r0 = rays + (size_t)pi[k] * kc * 7, *r1 = rays + (size_t)pl[k] * kc * 7;
             double nm = 0.0, dn = 0.0;
             for (int j = 0; j < kc; ++j) {
@@ -713,7 +738,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         const int i = pi[k], l = pl[k];
         if (i == l) { x[k] = 0.0; w[k] = a.w_sparse; continue; }
         double aff = 0.0;
-        if (view[i] != view[l]) {
+        if (!((sv >> k) & 1)) {
             double d = num[k] / (1e-5 + den[k]);
             d = d > thr ? thr : d;
             aff = 1.0 - d / thr;
@@ -733,6 +758,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     double shift = fma(1.0625, sqrt(sx), 0.5);
     for (int iter = 0; iter < a.max_iter; ++iter) {
         uint64_t tt0 = 0;
+        ++n_iter_all;
         if (trace) { tt0 = __builtin_amdgcn_s_memtime(); ++n_iter; }
         {
             const int row = lane % R, part = lane / R, j0 = part * CPL;
@@ -798,7 +824,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         for (int k = 0; k < KP; ++k) {
             if (!own[k]) continue;
             const int i = pi[k], l = pl[k];
-            const bool same_view = view[i] == view[l];
+            const bool same_view = (sv >> k) & 1;
             double xn = q[k] - (w[k] + y[k]) * inv_mu;        // :482
             if (same_view) xn = 0.0;                          // :485-487
             if (i == l) xn = 1.0;                             // :490
@@ -836,6 +862,22 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         const double v = (x[k] < a.min_affinity) ? 0.0 : x[k];
         out[i * n_max + l] = v;
         out[l * n_max + i] = v;
+    }
+    if (a.stats) {
+        // fp64 operations of this frame (p2s_get_assoc_stats): a column-pair step is one dot product and two columns of n
+        // rows updated plus ~50 operations of rotation arithmetic (the first step of a sweep also takes both norms); a
+        // pass has the warm-start product, the normalisation, V diag Vt for one triangle and the element-wise update
+        int cross = 0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) cross += (own[k] && pi[k] != pl[k] && !((sv >> k) & 1)) ? 1 : 0;
+        cross = (int)wave_sum_dpp((double)cross);
+        if (lane == 0) {
+            const unsigned long long nn = (unsigned long long)n;
+            const unsigned long long flops = (unsigned long long)n_sweeps * (nn * (nn / 2) * (8 * nn + 50) + (nn / 2) * 4 * nn) +
+                                             (unsigned long long)n_iter_all * (2 * nn * nn * nn + 3 * nn * nn + 3 * nn * (nn * (nn + 1) / 2) + 20 * (nn * (nn + 1) / 2)) +
+                                             (unsigned long long)cross * Kj * 17;
+            assoc_count(a, 1, (unsigned long long)n_iter_all, (unsigned long long)n_sweeps, flops);
+        }
     }
     if (trace) {
         lds_fence<1>();

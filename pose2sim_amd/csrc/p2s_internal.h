@@ -119,6 +119,7 @@ struct P2sAssocArgs {
     int32_t C, Kj, Nmax, max_iter;
     int32_t debug_mode;         // diagnostics only: 7 = per-frame phase timeline instead of the result (exp/assoc_trace.py)
     int32_t form;               // P2S_ASSOC_FORM_* (p2s_set_tuning: tests run both kernels on the same frames)
+    unsigned long long *stats;  // sharded counters (frames, ADMM passes, Jacobi sweeps, fp64 operations) or NULL
     double recon_thr, min_affinity, w_rank, tol, w_sparse;
 };
 

@@ -100,6 +100,13 @@ class Engine:
         _lib.check(self._lib.p2s_get_tri_stats(self._h, _ptr(out), 1 if reset else 0))
         return {'search_units': int(out[0]), 'subsets_evaluated': int(out[1]), 'passes': int(out[2]), 'capped_units': int(out[3])}
 
+    def assoc_stats(self, reset=False):
+        """Counters of this engine's multi-person association calls: frames with detections, ADMM passes, Jacobi sweeps,
+        fp64 operations (the kernels' own count)."""
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(self._lib.p2s_get_assoc_stats(self._h, _ptr(out), 1 if reset else 0))
+        return {'frames': int(out[0]), 'admm_passes': int(out[1]), 'jacobi_sweeps': int(out[2]), 'fp64_flops': int(out[3])}
+
     def set_tuning(self, key, value):
         _lib.check(self._lib.p2s_set_tuning(self._h, int(key), int(value)))
 

@@ -64,6 +64,26 @@ def test_golden_frames(engine, golden_dir):
     print(f'association: worst |d affinity| = {worst:.3e}')
 
 
+def test_counters(engine, golden_dir):
+    """p2s_get_assoc_stats: one count per frame with detections, passes within max_iter, a plausible operation count."""
+    i, g = next(iter(_assoc_groups(golden_dir)))
+    cal, frames = assoc_frames_of(g)
+    C, Kj = int(g['C']), int(g['Kj'])
+    P = [np.hstack([cal['K'][c], np.zeros((3, 1))]) @ np.vstack([np.hstack([cal['R_mat'][c], cal['T'][c].reshape(3, 1)]), [0, 0, 0, 1]]) for c in range(C)]
+    engine.set_calibration(P, cal)
+    n_persons, kpts = _pack(frames, C, Kj)
+    engine.assoc_stats(reset=True)
+    engine.associate(n_persons, kpts, engine.assoc_params(float(g['recon_thr']), float(g['min_aff']), int(g['min_cams']), max_iter=7))
+    st = engine.assoc_stats(reset=True)
+    nonempty = int((n_persons.sum(axis=1) > 0).sum())
+    assert st['frames'] == nonempty
+    assert nonempty <= st['admm_passes'] <= 7 * nonempty
+    assert st['admm_passes'] <= st['jacobi_sweeps'] <= 40 * st['admm_passes']
+    N = n_persons.sum(axis=1).astype(np.int64)
+    assert st['fp64_flops'] >= int((N ** 3).sum())          # at least one product per frame
+    assert engine.assoc_stats()['frames'] == 0
+
+
 def test_edge_frames(engine):
     """No detections at all, a single detection, one camera only."""
     from oracle import association_ref as ar
