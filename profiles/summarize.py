@@ -42,7 +42,12 @@ for f in glob.glob(os.path.join(SRC, 'bench_*.json')):
     shutil.copy(f, DST)
 stats = sorted(glob.glob(os.path.join(SRC, 'trace', '**', '*kernel_stats.csv'), recursive=True), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[-1], os.path.join(DST, 'kernel_stats_cfg2.csv'))
+    rows = list(csv.reader(open(stats[-1])))
+    for r in rows[1:]:                                      # torch's generator kernels have names of several KB
+        if len(r[0]) > 160:
+            r[0] = r[0][:150] + '...[name cut]'
+    with open(os.path.join(DST, 'kernel_stats_cfg2.csv'), 'w') as fh:
+        csv.writer(fh, quoting=csv.QUOTE_ALL).writerows(rows)
 
 # instruction mix / issue utilisation per kernel
 names = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAIT_INST_ANY']
