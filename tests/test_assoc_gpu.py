@@ -106,6 +106,45 @@ def test_edge_frames(engine):
             assert np.abs(aff[f, :N, :N] - ref).max() <= 1e-9
 
 
+@pytest.mark.parametrize('max_iter', [20, 3])
+def test_every_matrix_order(engine, max_iter):
+    """Frames of 1 .. 40 detections (odd and even orders, empty cameras, one frame per order): the symmetric one-wave
+    kernel up to 32 -- its 16-row form when the largest frame of a call has at most 16 -- and the general kernel
+    above, against the oracle; converged result and the continuous iterate after 3 passes."""
+    from oracle import association_ref as ar
+    C, Pn, Kj = 10, 4, 26
+    cams = synth.make_cameras(C, seed=21)
+    P = synth.projection_matrices(cams)
+    xyl = synth.make_observations(synth.make_points3d(40, Pn, Kj, seed=22), cams, seed=22, p_missing_cam=0.0, p_outlier=0.0)   # [F][Pn][C][K][3]
+    cal = {'inv_K': cams['inv_K'], 'R_mat': cams['R_mat'], 'T': cams['T']}
+    rng = np.random.default_rng(23)
+    frames = []
+    for total in range(1, 41):
+        counts = np.zeros(C, dtype=int)
+        for _ in range(total):                            # spread `total` detections over the cameras, at most Pn each
+            c = rng.choice(np.flatnonzero(counts < Pn))
+            counts[c] += 1
+        frames.append([[np.nan_to_num(xyl[total - 1, p, c]).astype(np.float32).astype(np.float64).ravel()
+                        for p in rng.permutation(Pn)[:counts[c]]] for c in range(C)])
+    engine.set_calibration(P, cams)
+    min_aff = 0.2 if max_iter == 20 else -1.0
+    prm = engine.assoc_params(0.1, min_aff, 2, max_iter=max_iter)
+    worst = 0.0
+    for lo, hi in ((0, 16), (0, 32), (0, 40)):            # largest frame of the call: 16, 32, 40 detections
+        n_persons, kpts = _pack(frames[lo:hi], C, Kj)
+        aff = engine.associate(n_persons, kpts.astype(np.float32), prm)
+        for f, per_cam in enumerate(frames[lo:hi]):
+            N = int(n_persons[f].sum())
+            cum = np.cumsum([0] + [len(p) for p in per_cam])
+            ref = ar.match_svt(ar.affinity_matrix(per_cam, cal, cum, 0.1), cum, max_iter=max_iter)
+            if max_iter == 20:
+                ref = np.where(ref < min_aff, 0.0, ref)
+            d = float(np.abs(aff[f, :N, :N] - ref).max())
+            worst = max(worst, d)
+            assert d <= 1e-9, (hi, N, d)
+    print(f'orders 1..40, max_iter {max_iter}: worst |d| = {worst:.3e}')
+
+
 def test_partial_iterations_match_oracle(engine, golden_dir):
     """The converged matchSVT result is binary; stopping the ADMM loop after 1, 2, 3 and 5 iterations
     exposes the continuous iterates (SVD-thresholded values), compared with the oracle at 1e-9."""
