@@ -500,16 +500,17 @@ __global__ void __launch_bounds__(64 * NW) p2s_assoc_kernel(const P2sAssocArgs a
 // moved into U.  With a shift c >= ||B||_F the matrix M = B + cI is positive definite: the one-sided Jacobi iteration
 // on M then needs NO accumulated V -- once the columns of G = M V are orthogonal, v_j = g_j / |g_j| and the
 // eigenvalue of B is lambda_j = |g_j| - c -- and Q = sum_j sgn(lambda_j) max(|lambda_j| - t, 0) v_j v_j^T.  That halves
-// the LDS traffic and the rotation work of a step and frees one LDS matrix.  What else is different from
-// p2s_assoc_kernel:
-//   * the squared column norms travel with the columns (alpha' = alpha - t gamma, beta' = beta + t gamma; stored in
-//     the padding element of each column, refreshed from the data in the first step of every sweep), so a step
-//     reduces one dot product over the L lanes of a column pair instead of three;
+// the rotation work of a step and frees one LDS matrix.  What else is different from p2s_assoc_kernel:
+//   * odd-even ordering with one column of every pair resident in registers (jacobi_oe below): one column read from
+//     LDS and one written per step;
+//   * the squared column norms travel with the columns (alpha' = alpha - t gamma, beta' = beta + t gamma; the first
+//     padding element of the LDS slot and a register, refreshed from the data in the first step of every sweep), so a
+//     step reduces one dot product over the L lanes of a column pair instead of three;
 //   * a step is issue bound, not latency bound (every fp64 or 32-bit VALU instruction costs a wave ~4 cycles of its
-//     SIMD), so the frame gets one wave (L = 4 lanes x 8 rows per column pair at 32 detections: the rotation's ~30
+//     SIMD), so the frame gets one wave (L = 4 lanes x 8 rows per column pair at 32 detections: the rotation's ~25
 //     scalar-like instructions are issued once per frame instead of once per wave of the frame) and the CU hides the
-//     chain latency with 12 frames = 3 waves per SIMD: G (n x (n+1)), the packed triangle of B and the view list are
-//     12 800 B of LDS, 10 allocation granules;
+//     chain latency with 12 frames = 3 waves per SIMD: G (32 x 34), the packed triangle of B (its last row in G's
+//     second padding element) and the view list are 12 800 B of LDS, 10 allocation granules of 1 280 B;
 //   * X, Y and W of matchSVT are symmetric element-wise state in the registers of the lane that owns the pair
 //     (lane + 64 k is the pair's index in the packed triangle), 9 pairs per lane;
 //   * the next pass starts from V of this one (G <- (B' + c'I) V: B changes little between ADMM passes).
@@ -631,8 +632,12 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     constexpr int PARTS = 64 / R, CPL = R / PARTS;  // warm-start product: lane = (row, part), CPL columns per lane
     extern __shared__ __align__(16) unsigned char smem[];
     double *G = reinterpret_cast<double *>(smem);   // [R][LD]; element R of a column: its squared norm, later its SVT weight
-    double *Bp = G + R * LD;                        // B[i][l] = B[l][i] at l (l + 1) / 2 + i, i <= l
-    int *view = reinterpret_cast<int *>(Bp + NPK);
+    // B[i][l] = B[l][i], i <= l, at packed index l (l + 1) / 2 + i: rows l < R - 1 behind G, the last row (R entries) in
+    // the second padding element of G's columns -- the 256 bytes between 11 and 12 frames per CU
+    constexpr int NPKS = NPK - R;
+    double *Bp = G + R * LD;
+    auto bp = [&](int idx) -> double * { return idx < NPKS ? Bp + idx : G + (idx - NPKS) * LD + (R + 1); };
+    int *view = reinterpret_cast<int *>(Bp + NPKS);
     double *rays = G;                               // [person][joint in chunk][7], aliases G and Bp
     const int lane = threadIdx.x;
     const int64_t f = blockIdx.x;
@@ -681,7 +686,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     if (trace) t_start = __builtin_amdgcn_s_memtime();
 
     // ---- rays + affinity accumulation, a chunk of joints at a time ------------------------------
-    int Kc = (R * LD + NPK) / (7 * N);
+    int Kc = (R * LD + NPKS) / (7 * N);
     Kc = max(1, min(Kc, Kj));
     for (int j0 = 0; j0 < Kj; j0 += Kc) {
         const int kc = min(Kc, Kj - j0);
@@ -729,7 +734,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     }
     // distance -> affinity (:397-406), circular constraint (:794-795), matchSVT initialisation (:467-475)
     const double thr = a.recon_thr;
-    for (int i = lane; i < R * LD + NPK; i += 64) G[i] = 0.0;          // G and Bp
+    for (int i = lane; i < R * LD + NPKS; i += 64) G[i] = 0.0;         // G (with the last row of B) and Bp
     lds_fence<1>();
     double sx = 0.0, sy = 0.0;                                         // ||X||_F^2, ||Y||_F^2 over the full matrices
 #pragma unroll
@@ -745,7 +750,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         }
         x[k] = aff;
         w[k] = a.w_sparse - aff;
-        Bp[lane + k * 64] = aff;                                       // B = X + Y/mu with Y = 0
+        *bp(lane + k * 64) = aff;                                      // B = X + Y/mu with Y = 0
         sx = fma(2.0 * aff, aff, sx);
     }
     sx = wave_sum_dpp(sx);
@@ -767,14 +772,14 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
 #pragma unroll
                 for (int jj = 0; jj < CPL; ++jj) {
                     const int j = j0 + jj, lo = min(row, j), hi = max(row, j);
-                    acc[jj] = Bp[hi * (hi + 1) / 2 + lo] + ((row == j && row < n) ? shift : 0.0);
+                    acc[jj] = *bp(hi * (hi + 1) / 2 + lo) + ((row == j && row < n) ? shift : 0.0);
                 }
             } else {                                          // warm start: G <- M V, V = the normalised columns of G
 #pragma unroll
                 for (int jj = 0; jj < CPL; ++jj) acc[jj] = shift * G[(j0 + jj) * LD + row];
                 int idx = row * (row + 1) / 2;
                 for (int kk = 0; kk < n; ++kk) {
-                    const double bk = Bp[idx];                // B[row][kk]
+                    const double bk = *bp(idx);               // B[row][kk]
                     idx += (kk < row) ? 1 : kk + 1;
 #pragma unroll
                     for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma(bk, G[(j0 + jj) * LD + kk], acc[jj]);
@@ -851,7 +856,7 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         // the next pass's SVT input, B = X + Y/mu (:480), from the owners
 #pragma unroll
         for (int k = 0; k < KP; ++k)
-            if (own[k]) Bp[lane + k * 64] = x[k] + y[k] * inv_mu;
+            if (own[k]) *bp(lane + k * 64) = x[k] + y[k] * inv_mu;
         lds_fence<1>();
     }
     // ---- min_affinity cut (:800) and store --------------------------------------------------------
@@ -893,7 +898,7 @@ hipError_t p2s_launch_assoc(const P2sAssocArgs &a, int dtype, hipStream_t s) {
     if (a.Nmax <= 32 && a.form != P2S_ASSOC_FORM_GENERAL) {           // symmetric form, one wave per frame
         auto go_s = [&](auto kern, int R) -> hipError_t {
             const int LD = R + (R == 32 ? 2 : 4);                 // R + L / 2, as in the kernel
-            const size_t lds = (size_t)(R * LD + R * (R + 1) / 2) * sizeof(double) + (size_t)R * sizeof(int);
+            const size_t lds = (size_t)(R * LD + R * (R - 1) / 2) * sizeof(double) + (size_t)R * sizeof(int);
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (err != hipSuccess) return err;
             hipLaunchKernelGGL(kern, dim3((unsigned)a.n_frames), dim3(64), lds, s, a);
