@@ -777,12 +777,16 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
             } else {                                          // warm start: G <- M V, V = the normalised columns of G
 #pragma unroll
                 for (int jj = 0; jj < CPL; ++jj) acc[jj] = shift * G[(j0 + jj) * LD + row];
+                // over all R rows of V, unrolled: the rows from n on are zero, and every LDS address is the lane's base
+                // plus an immediate offset (with a run-time trip count the 16 addresses cost two instructions per load)
                 int idx = row * (row + 1) / 2;
-                for (int kk = 0; kk < n; ++kk) {
+                const double *vrow = G + j0 * LD;
+#pragma unroll
+                for (int kk = 0; kk < R; ++kk) {
                     const double bk = *bp(idx);               // B[row][kk]
                     idx += (kk < row) ? 1 : kk + 1;
 #pragma unroll
-                    for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma(bk, G[(j0 + jj) * LD + kk], acc[jj]);
+                    for (int jj = 0; jj < CPL; ++jj) acc[jj] = fma(bk, vrow[jj * LD + kk], acc[jj]);
                 }
             }
             lds_fence<1>();                                   // every lane has read V before anyone overwrites it
