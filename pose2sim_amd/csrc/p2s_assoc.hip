@@ -628,7 +628,8 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     // the 32 / L groups of a half wave start L banks apart and the L lanes of a group fill the gap -- no conflicts.
     constexpr int LD = R + L / 2;
     constexpr int NPK = R * (R + 1) / 2;            // packed triangle of B
-    constexpr int KP = (NPK + 63) / 64;             // pairs per lane
+    constexpr int KP = (NPK + 63) / 64;             // pairs per lane while the affinity accumulates (pair lane + 64 k)
+    constexpr int KR = (R == 32) ? 11 : 3;          // pairs per lane in the ADMM loop: up to KR neighbours of one matrix row
     constexpr int PARTS = 64 / R, CPL = R / PARTS;  // warm-start product: lane = (row, part), CPL columns per lane
     extern __shared__ __align__(16) unsigned char smem[];
     double *G = reinterpret_cast<double *>(smem);   // [R][LD]; element R of a column: its squared norm, later its SVT weight
@@ -659,10 +660,14 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the zeros land before the result of another lane
     if (N == 0) return;
 
-    // the pairs this lane owns
+    // Two ways of dealing the n (n + 1) / 2 pairs (i <= l) of the symmetric matrices to the lanes.  While the affinity
+    // accumulates: pair lane + 64 k of the packed triangle, KP per lane, evenly loaded.  In the ADMM loop: up to KR
+    // consecutive i of ONE row l per lane (rows of more than KR entries are cut into equal chunks: 63 chunks at
+    // R = 32), so that rebuilding Q = V diag(h) V^T reads one element of every column for the row and KR consecutive
+    // ones for the i -- two base addresses and immediate offsets instead of 2 KP scattered addresses per column.
     int pi[KP], pl[KP];
     bool own[KP];                                   // a pair of real detections (not the zero padding)
-    double x[KP], y[KP], w[KP], num[KP], den[KP];
+    double num[KP], den[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         const int pr = lane + k * 64;
@@ -672,8 +677,8 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         pl[k] = l;
         pi[k] = pr - l * (l + 1) / 2;               // i <= l
         own[k] = l < N;
-        if (!own[k]) { pl[k] = 0; pi[k] = 0; }      // harmless addresses for the loads of the product below
-        x[k] = 0.0; y[k] = 0.0; w[k] = 0.0; num[k] = 0.0; den[k] = 0.0;
+        if (!own[k]) { pl[k] = 0; pi[k] = 0; }
+        num[k] = 0.0; den[k] = 0.0;
     }
     unsigned sv = 0;                                // bit k: the two detections of pair k are in the same view (or are the same)
 #pragma unroll
@@ -737,24 +742,44 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
     for (int i = lane; i < R * LD + NPKS; i += 64) G[i] = 0.0;         // G (with the last row of B) and Bp
     lds_fence<1>();
     double sx = 0.0, sy = 0.0;                                         // ||X||_F^2, ||Y||_F^2 over the full matrices
+    int cross = 0;                                                     // cross-view pairs (p2s_get_assoc_stats)
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
-        if (!own[k]) continue;
-        const int i = pi[k], l = pl[k];
-        if (i == l) { x[k] = 0.0; w[k] = a.w_sparse; continue; }
-        double aff = 0.0;
-        if (!((sv >> k) & 1)) {
-            double d = num[k] / (1e-5 + den[k]);
-            d = d > thr ? thr : d;
-            aff = 1.0 - d / thr;
-        }
-        x[k] = aff;
-        w[k] = a.w_sparse - aff;
+        if (!own[k] || ((sv >> k) & 1)) continue;                      // the diagonal and same-view pairs stay 0
+        double d = num[k] / (1e-5 + den[k]);
+        d = d > thr ? thr : d;
+        const double aff = 1.0 - d / thr;
         *bp(lane + k * 64) = aff;                                      // B = X + Y/mu with Y = 0
         sx = fma(2.0 * aff, aff, sx);
+        ++cross;
     }
     sx = wave_sum_dpp(sx);
     lds_fence<1>();
+    // the ADMM loop's pairs: row rl, columns ri0 .. ri0 + rcnt - 1
+    int rl = 0, ri0 = 0, rcnt = 0;
+    {
+        int first = 0;                                                 // first chunk of row l
+        for (int l = 0; l < R; ++l) {
+            const int m = l + 1, c = (m + KR - 1) / KR, sz = (m + c - 1) / c;
+            if (lane >= first && lane < first + c) { rl = l; ri0 = (lane - first) * sz; rcnt = min(sz, m - ri0); }
+            first += c;
+        }
+        if (rl >= N) rcnt = 0;                                         // zero padding is not part of the problem
+    }
+    double *const pb = bp(rl * (rl + 1) / 2 + ri0);                    // B[rl][ri0 + k] at pb[k * pbs]
+    const int pbs = (rl == R - 1) ? LD : 1;
+    const int dk = rl - ri0;                                           // the diagonal element is pair dk (if < rcnt)
+    unsigned sv_r = 0;                                                 // bit k: same view (or the diagonal)
+    double x[KR], y[KR], w[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        const bool mine = k < rcnt;
+        const int kk = mine ? k : 0;                                   // a valid address for the lanes without pair k
+        sv_r |= (mine && view[ri0 + kk] == view[rl]) ? (1u << k) : 0u;
+        x[k] = mine ? pb[kk * pbs] : 0.0;                              // X = the affinity, 0 on the diagonal (:467-475)
+        w[k] = a.w_sparse - x[k];
+        y[k] = 0.0;
+    }
     if (trace) t_aff = __builtin_amdgcn_s_memtime() - t_start;
 
     // ---- matchSVT (:477-505) --------------------------------------------------------------
@@ -818,29 +843,31 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
             }
         }
         lds_fence<1>();
-        double q[KP];
+        double q[KR];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) q[k] = 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double *col = G + j * LD;
-            const double hj = col[R];
+        for (int k = 0; k < KR; ++k) q[k] = 0.0;
+        {
+            const double *gl = G + rl, *gi = G + ri0;
+#pragma unroll 2
+            for (int j = 0; j < n; ++j) {
+                const double hl = G[j * LD + R] * gl[j * LD];               // h_j v_j[l]
 #pragma unroll
-            for (int k = 0; k < KP; ++k) q[k] = fma(hj * col[pi[k]], col[pl[k]], q[k]);
+                for (int k = 0; k < KR; ++k) q[k] = fma(hl, gi[j * LD + k], q[k]);
+            }
         }
         double pres2 = 0.0, dres2 = 0.0;
         sx = 0.0; sy = 0.0;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            if (!own[k]) continue;
-            const int i = pi[k], l = pl[k];
-            const bool same_view = (sv >> k) & 1;
+        for (int k = 0; k < KR; ++k) {
+            if (k >= rcnt) continue;
+            const bool diag = k == dk;
             double xn = q[k] - (w[k] + y[k]) * inv_mu;        // :482
-            if (same_view) xn = 0.0;                          // :485-487
-            if (i == l) xn = 1.0;                             // :490
+            if ((sv_r >> k) & 1) xn = 0.0;                    // :485-487
+            if (diag) xn = 1.0;                               // :490
             xn = xn < 0.0 ? 0.0 : xn; xn = xn > 1.0 ? 1.0 : xn;   // :491-492
             // :495 multiplies the same-view entries by 0 once more; :496 (X + X.T) / 2 of a symmetric X is X
             const double dq = xn - q[k], dx = xn - x[k];
-            const double mult = (i == l) ? 1.0 : 2.0;         // both triangles
+            const double mult = diag ? 1.0 : 2.0;             // both triangles
             y[k] = fma(mu, dq, y[k]);                         // :497
             pres2 = fma(mult * dq, dq, pres2);
             dres2 = fma(mult * dx, dx, dres2);
@@ -859,26 +886,22 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
         shift = fma(1.0625, sqrt(sx) + sqrt(sy) * inv_mu, 0.5);
         // the next pass's SVT input, B = X + Y/mu (:480), from the owners
 #pragma unroll
-        for (int k = 0; k < KP; ++k)
-            if (own[k]) *bp(lane + k * 64) = x[k] + y[k] * inv_mu;
+        for (int k = 0; k < KR; ++k)
+            if (k < rcnt) pb[k * pbs] = x[k] + y[k] * inv_mu;
         lds_fence<1>();
     }
     // ---- min_affinity cut (:800) and store --------------------------------------------------------
 #pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        if (!own[k]) continue;
-        const int i = pi[k], l = pl[k];
+    for (int k = 0; k < KR; ++k) {
+        if (k >= rcnt) continue;
         const double v = (x[k] < a.min_affinity) ? 0.0 : x[k];
-        out[i * n_max + l] = v;
-        out[l * n_max + i] = v;
+        out[(ri0 + k) * n_max + rl] = v;
+        out[rl * n_max + ri0 + k] = v;
     }
     if (a.stats) {
         // fp64 operations of this frame (p2s_get_assoc_stats): a column-pair step is one dot product and two columns of n
         // rows updated plus ~50 operations of rotation arithmetic (the first step of a sweep also takes both norms); a
         // pass has the warm-start product, the normalisation, V diag Vt for one triangle and the element-wise update
-        int cross = 0;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) cross += (own[k] && pi[k] != pl[k] && !((sv >> k) & 1)) ? 1 : 0;
         cross = (int)wave_sum_dpp((double)cross);
         if (lane == 0) {
             const unsigned long long nn = (unsigned long long)n;
