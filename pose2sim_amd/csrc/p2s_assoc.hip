@@ -802,12 +802,9 @@ __global__ void __launch_bounds__(64, 3) p2s_assoc_kernel_s(const P2sAssocArgs a
             } else {                                          // warm start: G <- M V, V = the normalised columns of G
 #pragma unroll
                 for (int jj = 0; jj < CPL; ++jj) acc[jj] = shift * G[(j0 + jj) * LD + row];
-                // over all R rows of V, unrolled: the rows from n on are zero, and every LDS address is the lane's base
-                // plus an immediate offset (with a run-time trip count the 16 addresses cost two instructions per load)
                 int idx = row * (row + 1) / 2;
                 const double *vrow = G + j0 * LD;
-#pragma unroll
-                for (int kk = 0; kk < R; ++kk) {
+                for (int kk = 0; kk < n; ++kk) {                  // rolled: unrolled by 4 or fully it spills and is 3-4 % slower
                     const double bk = *bp(idx);               // B[row][kk]
                     idx += (kk < row) ? 1 : kk + 1;
 #pragma unroll
