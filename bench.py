@@ -364,6 +364,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pool-singles', type=int, default=-1, help='kernel experiments: P2S_TUNE_POOL_SINGLES_PCT')
+    ap.add_argument('--tri-path', default='auto', choices=['auto', 'worklist', 'onetile'], help='kernel experiments (p2s_set_tuning)')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -437,6 +439,10 @@ def main():
     dev = torch.device('cuda', local_rank)
     eng = Engine(local_rank)
     eng.set_calibration(P, cams)
+    if args.pool_singles >= 0:
+        eng.set_tuning(Engine.TUNE_POOL_SINGLES_PCT, args.pool_singles)
+    if args.tri_path != 'auto':
+        eng.set_tuning(Engine.TUNE_TRI_PATH, {'worklist': Engine.TRI_PATH_WORKLIST, 'onetile': Engine.TRI_PATH_ONE_TILE}[args.tri_path])
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     prm = Engine.tri_params(cfg['thr'], cfg['lik'], cfg['min_cams'], cfg['undistort'], cfg['lr_swap'])
 
@@ -550,6 +556,7 @@ def main():
                                   'undistort': cfg['undistort'], 'lr_swap': cfg['lr_swap']},
                        'accepted_fraction': ok_frac,
                        'search': {'units_entering_search_per_step': stats['search_units'], 'subsets_evaluated_per_step': stats['subsets_evaluated'],
+                                  'evaluation_passes_per_step': stats['passes'],
                                   'capped_units_per_step': stats['capped_units']},
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -85,6 +85,7 @@ struct p2s_ctx {
     uint32_t max_subsets = P2S_MAX_SUBSETS_PER_LEVEL;
     int debug_mode = 0;                              // honoured by a -DP2S_DIAG build only
     int assoc_form = P2S_ASSOC_FORM_AUTO;
+    int pool_singles_pct = 8;                        // p2s_tri_pool.hip: share of the tiles that the last workgroups take one at a time
 };
 
 namespace {
@@ -361,7 +362,7 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
     switch (key) {
     case P2S_TUNE_TRI_PATH:
-        if (value != P2S_TRI_PATH_AUTO && value != P2S_TRI_PATH_WORKLIST)
+        if (value != P2S_TRI_PATH_AUTO && value != P2S_TRI_PATH_WORKLIST && value != P2S_TRI_PATH_ONE_TILE)
             return fail(P2S_ERR_INVALID_ARG, "unknown triangulation path %d", value);
         ctx->tri_path = value;
         return P2S_OK;
@@ -378,6 +379,10 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
     case P2S_TUNE_DEEP_MIN_SUBSETS:
         if (value < 0) return fail(P2S_ERR_INVALID_ARG, "deep-level threshold must be >= 0");
         ctx->deep_min_subsets = (uint32_t)value;
+        return P2S_OK;
+    case P2S_TUNE_POOL_SINGLES_PCT:
+        if (value < 0 || value > 100) return fail(P2S_ERR_INVALID_ARG, "percentage outside [0, 100]");
+        ctx->pool_singles_pct = value;
         return P2S_OK;
     case P2S_TUNE_ASSOC_FORM:
         if (value != P2S_ASSOC_FORM_AUTO && value != P2S_ASSOC_FORM_GENERAL)
@@ -417,8 +422,10 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     if (((uintptr_t)d_xyl & 15) != 0) return fail(P2S_ERR_INVALID_ARG, "xyl must be 16-byte aligned");
     const int C = ctx->n_cams;
     const int elem = dtype == P2S_F32 ? 4 : 8;
-    if (ctx->tri_path == P2S_TRI_PATH_AUTO && !ctx->force_tiled &&
+    if (ctx->tri_path != P2S_TRI_PATH_WORKLIST && !ctx->force_tiled &&
         p2s_tri_fused_supports(C, dtype, params->undistort_points, params->handle_lr_swap)) {
+        const bool pooled = ctx->tri_path == P2S_TRI_PATH_AUTO &&
+                            p2s_tri_pool_supports(C, dtype, params->undistort_points, params->handle_lr_swap);
         // one launch per chunk: streaming pass + in-wave subset search (p2s_tri_fused.hip).  A chunk keeps the
         // kernel's 32-bit byte offsets below 2^31 and starts on a multiple of 16 blocks (16-byte result stores).
         P2sTriArgs a{};
@@ -438,7 +445,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         for (int64_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks) {
             a.block0 = b0;
             a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - b0);
-            HIP_TRY(p2s_launch_tri_fused(a, dtype, ctx->stream));
+            HIP_TRY(pooled ? p2s_launch_tri_pool(a, ctx->pool_singles_pct, ctx->stream) : p2s_launch_tri_fused(a, dtype, ctx->stream));
         }
         return P2S_OK;
     }

@@ -89,8 +89,8 @@ class Engine:
 
     # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
     TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS, TUNE_DEEP_MIN_SUBSETS = 1, 2, 3, 4, 5, 6, 7
-    TUNE_ASSOC_FORM = 8
-    TRI_PATH_AUTO, TRI_PATH_WORKLIST = 0, 1
+    TUNE_ASSOC_FORM, TUNE_POOL_SINGLES_PCT = 8, 9
+    TRI_PATH_AUTO, TRI_PATH_WORKLIST, TRI_PATH_ONE_TILE = 0, 1, 2
     ASSOC_FORM_AUTO, ASSOC_FORM_GENERAL = 0, 1
 
     def tri_stats(self, reset=False):

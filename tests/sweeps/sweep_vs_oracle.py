@@ -11,6 +11,8 @@ eng = Engine(0)
 # P2S_SWEEP_PATH=worklist: the streaming + work-list search pair everywhere (default: the one-launch kernel where it applies)
 if os.environ.get('P2S_SWEEP_PATH') == 'worklist':
     eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST)
+if os.environ.get('P2S_SWEEP_PATH') == 'onetile':      # the one-tile-per-wave kernel wherever a one-launch kernel applies
+    eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_ONE_TILE)
 threads = min(128, len(os.sched_getaffinity(0)))
 cases = [
     dict(name='cfg2', F=100_000, C=8, K=26, min_cams=2, seed=2),

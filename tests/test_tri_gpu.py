@@ -21,13 +21,14 @@ TOL_Q = 1e-7        # metres
 TOL_E = 2e-6        # px, relative to max(1, err)
 
 
-@pytest.fixture(scope='module', params=['auto', 'worklist'])
+@pytest.fixture(scope='module', params=['auto', 'worklist', 'onetile'])
 def engine(request):
     import __graft_entry__ as entry
     entry.build_hip()
     from pose2sim_amd.engine import Engine
     eng = Engine(0)
-    eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST if request.param == 'worklist' else Engine.TRI_PATH_AUTO)
+    eng.set_tuning(Engine.TUNE_TRI_PATH, {'auto': Engine.TRI_PATH_AUTO, 'worklist': Engine.TRI_PATH_WORKLIST,
+                                          'onetile': Engine.TRI_PATH_ONE_TILE}[request.param])
     yield eng
     eng.close()
 
