@@ -94,7 +94,11 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_pool_kernel(const P2sTriArgs a)
     const uint32_t xj = blockIdx.x >> 3;
     if (xj >= a.pool_pairs + a.pool_singles) return;
     const bool paired = xj < a.pool_pairs;
-    const uint32_t tile0 = (blockIdx.x & 7u) * per_xcd + (paired ? TPW * xj : TPW * a.pool_pairs + (xj - a.pool_pairs));
+    // A paired workgroup takes tiles xj and xj + pairs of the range (not two neighbours): neighbouring tiles share the
+    // cache lines at their common edge, and this way they are still streamed by neighbouring workgroups at about the
+    // same time (as neighbours of one wave, 16 us apart, the edge lines had left the L2: +16 % fetched bytes).
+    const uint32_t tstride = paired ? a.pool_pairs : 0u;
+    const uint32_t tile0 = (blockIdx.x & 7u) * per_xcd + (paired ? xj : TPW * a.pool_pairs + (xj - a.pool_pairs));
     const int my_tiles = paired ? TPW : 1;
     if (tile0 >= n_tiles) return;
     const double thr = a.thr;
@@ -158,11 +162,11 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_pool_kernel(const P2sTriArgs a)
     bool act0, act1 = false, act2 = false;
     const uint32_t u0 = unit_of(tile0, act0);
     load_obs<T, CT, EXACT>(a, C, u0 / (uint32_t)K, u0 % (uint32_t)K, obs0);
-    const bool two = my_tiles > 1 && tile0 + 1 < n_tiles;
-    const bool three = TPW > 2 && my_tiles > 2 && tile0 + 2 < n_tiles;
+    const bool two = my_tiles > 1 && tile0 + tstride < n_tiles;
+    const bool three = TPW > 2 && my_tiles > 2 && tile0 + 2 * tstride < n_tiles;
     level0(0, act0, obs0, [&](double dep) {
         if (two) {
-            uint32_t u1 = unit_of(tile0 + 1, act1);
+            uint32_t u1 = unit_of(tile0 + tstride, act1);
             asm volatile("" : "+v"(u1) : "v"(dep));                     // not before the eigen-solve
             load_obs<T, CT, EXACT>(a, C, u1 / (uint32_t)K, u1 % (uint32_t)K, obs1);
         }
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_pool_kernel(const P2sTriArgs a)
     if (two) level0(1, act1, obs1, [&](double dep) {
         if constexpr (TPW > 2) {
             if (three) {
-                uint32_t u2 = unit_of(tile0 + 2, act2);
+                uint32_t u2 = unit_of(tile0 + 2 * tstride, act2);
                 asm volatile("" : "+v"(u2) : "v"(dep));
                 load_obs<T, CT, EXACT>(a, C, u2 / (uint32_t)K, u2 % (uint32_t)K, obs2);
             }
@@ -191,7 +195,7 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_pool_kernel(const P2sTriArgs a)
                 wsync();
                 if (lane < cnt) {
                     const int o = sOver[first - kSlots + lane];
-                    const uint32_t u = ((tile0 + (uint32_t)(o >> 6)) << 6) + (uint32_t)(o & 63);
+                    const uint32_t u = ((tile0 + (uint32_t)(o >> 6) * tstride) << 6) + (uint32_t)(o & 63);
                     const uint32_t b = u / (uint32_t)K, k = u - b * (uint32_t)K;
                     RegObs<T, CT> ob;
                     ob.lik_thr = a.lik_thr;
@@ -318,8 +322,8 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_pool_kernel(const P2sTriArgs a)
     wsync();
 #pragma unroll 1
     for (int t = 0; t < my_tiles; ++t) {
-        const uint32_t tile = tile0 + t;
-        if (tile >= n_tiles) break;
+        const uint32_t tile = tile0 + t * tstride;
+        if (tile >= n_tiles) continue;
         const int64_t wave_u0 = (int64_t)tile << 6;
         const int64_t gu0 = a.block0 * K + wave_u0;
         const int64_t n_left = n_units - wave_u0;
