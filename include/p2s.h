@@ -197,9 +197,9 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 /* Experiments and tests only -- apart from P2S_TUNE_MAX_SUBSETS nothing here changes a result, and the library never
  * reads the environment.
  *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernels with the in-wave subset search where they
- *                         apply (pinhole, no L/R swap: two tiles per wave with pooled searching units for float32 input
- *                         and up to 8 cameras, one tile per wave up to 16 cameras), else the streaming + work-list
- *                         search pair; P2S_TRI_PATH_ONE_TILE: the one-tile-per-wave kernel wherever a one-launch kernel
+ *                         apply (pinhole, no L/R swap, up to 16 cameras: p2s_tri_pool.hip for float32 input -- two tiles per
+ *                         wave with pooled searching units up to 8 cameras -- p2s_tri_fused.hip for float64), else the
+ *                         streaming + work-list search pair; P2S_TRI_PATH_ONE_TILE: the one-tile-per-wave kernel wherever a one-launch kernel
  *                         applies; P2S_TRI_PATH_WORKLIST: always the pair
  *   P2S_TUNE_POOL_SINGLES_PCT  share (%) of the tiles that the last workgroups of every XCD take one at a time instead
  *                         of two in the pooled kernel (default 8)

@@ -8,8 +8,8 @@
 // observations go to its LDS slot with its normal matrix -- nobody else's are staged -- and the unit is looked after
 // by the lane with the slot's number, not by the lane that streamed it.
 //
-// Scope: float32 observations, up to 8 cameras, pinhole, no L/R swap (BASELINE configs[1] and every shipped demo);
-// p2s_tri_fused.hip keeps 9-16 cameras and float64 input.  On configs[1]: 6 % fewer vector instructions, 3.5 % less time.
+// Scope: float32 observations, pinhole, no L/R swap (every shipped configuration): two tiles per wave up to 8 cameras
+// (BASELINE configs[1]), one tile per wave from 9 to 16 (configs[3]); p2s_tri_fused.hip keeps float64 input.  On configs[1]: 6 % fewer vector instructions, 3.5 % less time.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -377,11 +377,14 @@ hipError_t launch_pool(P2sTriArgs a, int singles_pct, hipStream_t s) {
 }  // namespace
 
 bool p2s_tri_pool_supports(int C, int dtype, int undistort, int lr_swap) {
-    return !undistort && !lr_swap && dtype == 0 && C <= 8;
+    return !undistort && !lr_swap && dtype == 0 && C <= 16;
 }
 
 hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int singles_pct, hipStream_t s) {
     // two tiles per wave: three (14.6 KB of LDS, 11 waves per CU) have 6 % fewer passes again and take 2 % longer
     if (a.C <= 4) return launch_pool<float, 4, 2>(a, singles_pct, s);
+    // 9-16 cameras: ONE tile per wave -- what is left is the slot-resident staging: 12.7 KB of LDS instead of the 19.6 KB
+    // of p2s_tri_fused_kernel, a third wave per SIMD, 2.6 % on the 16-camera shard (two tiles: 16.3 KB, spills, 22 % slower)
+    if (a.C > 8) return launch_pool<float, 16, 1>(a, 100, s);
     return launch_pool<float, 8, 2>(a, singles_pct, s);
 }
