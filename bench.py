@@ -563,9 +563,8 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'fp64_frac': flops / (k_ms * 1e-3) / FP64_PEAK, 'fp64_tflops': flops / (k_ms * 1e-3) / 1e12,
                          'fp64_flop_per_step': flops,
-                         'kernel': (('p2s_tri_pool_kernel (streaming pass + in-wave subset search of the wave\'s pooled failures, one launch)'
-                                     if args.tri_path == 'auto' else
-                                     'p2s_tri_fused_kernel (streaming pass + in-wave subset search, one launch)') if (fused and args.tri_path != 'worklist') else
+                         'kernel': ('p2s_tri_fused_kernel (streaming pass + in-wave subset search of the wave\'s pooled failures, one launch)'
+                                    if (fused and args.tri_path != 'worklist') else
                                     'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)'),
                          'kernel_ms': k_ms, 'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }

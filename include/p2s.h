@@ -196,13 +196,13 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 
 /* Experiments and tests only -- apart from P2S_TUNE_MAX_SUBSETS nothing here changes a result, and the library never
  * reads the environment.
- *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernels with the in-wave subset search where they
- *                         apply (pinhole, no L/R swap, up to 16 cameras: p2s_tri_pool.hip for float32 input -- two tiles per
- *                         wave with pooled searching units up to 8 cameras -- p2s_tri_fused.hip for float64), else the
- *                         streaming + work-list search pair; P2S_TRI_PATH_ONE_TILE: the one-tile-per-wave kernel wherever a one-launch kernel
- *                         applies; P2S_TRI_PATH_WORKLIST: always the pair
+ *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernel with the in-wave subset search where it
+ *                         applies (pinhole, no L/R swap, up to 16 cameras; two tiles per wave with pooled searching units
+ *                         for float32 input and up to 8 cameras), else the streaming + work-list search pair;
+ *                         P2S_TRI_PATH_ONE_TILE: the one-launch kernel with one tile per wave everywhere;
+ *                         P2S_TRI_PATH_WORKLIST: always the pair
  *   P2S_TUNE_POOL_SINGLES_PCT  share (%) of the tiles that the last workgroups of every XCD take one at a time instead
- *                         of two in the pooled kernel (default 8)
+ *                         of two (default 8)
  *   P2S_TUNE_FORCE_TILED  1: the LDS-tiled streaming kernel even where observations fit in registers
  *   P2S_TUNE_NO_OVERLAP   1: search kernels on the main stream instead of beside the next chunk's streaming pass
  *   P2S_TUNE_SEARCH_JOB   work-list records a search wave takes at a time (8..64; 0 = automatic)

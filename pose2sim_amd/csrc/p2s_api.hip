@@ -85,7 +85,7 @@ struct p2s_ctx {
     uint32_t max_subsets = P2S_MAX_SUBSETS_PER_LEVEL;
     int debug_mode = 0;                              // honoured by a -DP2S_DIAG build only
     int assoc_form = P2S_ASSOC_FORM_AUTO;
-    int pool_singles_pct = 8;                        // p2s_tri_pool.hip: share of the tiles that the last workgroups take one at a time
+    int pool_singles_pct = 8;                        // p2s_tri_fused.hip: share of the tiles that the last workgroups take one at a time
 };
 
 namespace {
@@ -424,8 +424,6 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     const int elem = dtype == P2S_F32 ? 4 : 8;
     if (ctx->tri_path != P2S_TRI_PATH_WORKLIST && !ctx->force_tiled &&
         p2s_tri_fused_supports(C, dtype, params->undistort_points, params->handle_lr_swap)) {
-        const bool pooled = ctx->tri_path == P2S_TRI_PATH_AUTO &&
-                            p2s_tri_pool_supports(C, dtype, params->undistort_points, params->handle_lr_swap);
         // one launch per chunk: streaming pass + in-wave subset search (p2s_tri_fused.hip).  A chunk keeps the
         // kernel's 32-bit byte offsets below 2^31 and starts on a multiple of 16 blocks (16-byte result stores).
         P2sTriArgs a{};
@@ -445,7 +443,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         for (int64_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks) {
             a.block0 = b0;
             a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - b0);
-            HIP_TRY(pooled ? p2s_launch_tri_pool(a, ctx->pool_singles_pct, ctx->stream) : p2s_launch_tri_fused(a, dtype, ctx->stream));
+            HIP_TRY(p2s_launch_tri_fused(a, dtype, ctx->tri_path == P2S_TRI_PATH_ONE_TILE ? 100 : ctx->pool_singles_pct, ctx->stream));
         }
         return P2S_OK;
     }

@@ -66,7 +66,7 @@ struct P2sTriArgs {
     uint32_t *deep_ctl;          //   exported here (NULL: every level is walked in the wave)
     uint32_t deep_capacity, deep_entry_bytes, deep_min_subsets;
     uint32_t max_subsets;        // search kernel: a level with more subsets is not entered (P2S_MAX_SUBSETS_PER_LEVEL unless tuned)
-    uint32_t pool_pairs, pool_singles;   // p2s_tri_pool.hip: per XCD, workgroups that take two tiles, then workgroups that take one
+    uint32_t pool_pairs, pool_singles;   // p2s_tri_fused.hip: per XCD, workgroups that take two tiles, then workgroups that take one
     int32_t job;                 // work-list records a search wave takes at a time (<= 64); sizes its LDS region
     int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
     double thr, lik_thr;
@@ -126,12 +126,10 @@ struct P2sAssocArgs {
 
 hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g, hipStream_t s, hipStream_t side,
                           hipEvent_t k1_done);
-// p2s_tri_fused.hip: streaming pass + in-wave subset search in one launch (pinhole, no L/R swap, C <= 16)
+// p2s_tri_fused.hip: streaming pass + in-wave subset search in one launch (pinhole, no L/R swap, C <= 16); up to 8
+// cameras two tiles per wave, except for the last singles_pct % of every XCD's tiles
 bool p2s_tri_fused_supports(int C, int dtype, int undistort, int lr_swap);
-hipError_t p2s_launch_tri_fused(const P2sTriArgs &a, int dtype, hipStream_t s);
-// p2s_tri_pool.hip: the same with two tiles per wave and their searching units pooled (float32 input, C <= 8)
-bool p2s_tri_pool_supports(int C, int dtype, int undistort, int lr_swap);
-hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int singles_pct, hipStream_t s);
+hipError_t p2s_launch_tri_fused(const P2sTriArgs &a, int dtype, int singles_pct, hipStream_t s);
 struct P2sSingleArgs {
     const int32_t *n_persons;   // [F][C]
     const int64_t *offsets;     // [F+1]

@@ -11,7 +11,7 @@ eng = Engine(0)
 # P2S_SWEEP_PATH=worklist: the streaming + work-list search pair everywhere (default: the one-launch kernel where it applies)
 if os.environ.get('P2S_SWEEP_PATH') == 'worklist':
     eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST)
-if os.environ.get('P2S_SWEEP_PATH') == 'onetile':      # the one-tile-per-wave kernel wherever a one-launch kernel applies
+if os.environ.get('P2S_SWEEP_PATH') == 'onetile':      # the one-launch kernel with one tile per wave everywhere
     eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_ONE_TILE)
 threads = min(128, len(os.sched_getaffinity(0)))
 cases = [
