@@ -261,7 +261,9 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_fused_kernel(const P2sTriArgs a
                         bool go = has && (r < nsub);
                         uint32_t S = 0;
                         if (go) {
-                            S = a.sub_tab[sub0 + r];
+                            // level 1 is rank r <-> camera r (itertools.combinations order); only the deeper levels go to
+                            // the table in global memory (a load per pass, and its latency)
+                            S = (level == 1) ? (1u << r) : (uint32_t)a.sub_tab[sub0 + r];
                             // quirk Q1 duplicates: only the lexicographically first padding can win the argmin
                             const uint32_t pad = S & o_d;
                             const uint32_t below = pad ? ((2u << (31 - __builtin_clz(pad))) - 1u) : 0u;
