@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(64) p2s_deep_plan_kernel(const P2sDeepArgs d, 
         if (take) {
             e->first_ticket = first;
             e->n_chunks = chunks;
+            e->pad0 = 0;                                    // "a plain candidate of this level is under the threshold" (eval kernel)
             for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[first + c] = i; d.sched_chunk[first + c] = c; }
         }
         const unsigned long long taken = __ballot(take);
@@ -137,9 +138,16 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
         uint32_t brank = kNone, bS = 0;
         double se = kInf, sq0 = d_nan(), sq1 = d_nan(), sq2 = d_nan();
         uint32_t srank = kNone, sS = 0;
+        // The swap candidates of a level count only if its plain minimum stays above the threshold (triangulation.py:509),
+        // which no single chunk knows -- but once ANY chunk has seen a plain candidate under the threshold they cannot
+        // count any more: the wave that sees one raises a flag in the entry, and every wave stops evaluating swap
+        // candidates of that entry from its next round on.  Exact whatever the timing: the reduction ignores them then.
+        uint32_t *plain_ok = const_cast<uint32_t *>(&e->pad0);
+        bool skip_swap = false;
         for (uint32_t r0 = r_begin; r0 < r_end; r0 += 64) {
             const uint32_t r = r0 + lane;
             bool go = r < r_end;
+            if (LRSWAP && !skip_swap) skip_swap = __hip_atomic_load(plain_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             uint32_t S = 0;
             if (go) {
                 S = unrank_subset(r, C, level, sBinom);
@@ -168,7 +176,11 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
             const double err = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
             if (go && (err < be || brank == kNone)) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
-            if (LRSWAP && M > 2) {
+            if (LRSWAP && !skip_swap && __any(go && err <= thr)) {
+                skip_swap = true;
+                if (lane == 0) atomicOr(plain_ok, 1u);
+            }
+            if (LRSWAP && M > 2 && !skip_swap) {
                 // the swap candidate counts only if the level's plain minimum stays above the threshold, which no
                 // single wave knows: every chunk evaluates it, the reduction decides (triangulation.py:509)
                 double qs[3];
