@@ -310,6 +310,31 @@ def test_cfg4_shape_every_unit_against_the_oracle(engine):
     assert np.array_equal(ns, nex[1:778]) and np.array_equal(ms, mask[1:778])
 
 
+@pytest.mark.parametrize('singles_pct', [0, 8, 50, 100])
+@pytest.mark.parametrize('C,p_outlier,F', [(8, 0.30, 1_237), (6, 0.20, 2_001), (8, 0.03, 5_003)])
+def test_pooled_search_slots_and_tile_pairing(C, p_outlier, F, singles_pct):
+    """The one-launch kernel's bookkeeping, every unit against the C oracle: far more searching units per wave than
+    its 32 slots hold (30 % gross outliers: further rounds that read the observations again), tile counts that are not
+    a multiple of the 8 XCD ranges or of the pair size, and every split of a range into paired and single tiles."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from oracle import tri_oracle
+    from pose2sim_amd.engine import Engine
+    from pose2sim_amd import synth
+    wl = synth.make_config(F, C, 26, 1, seed=500 + C, p_outlier=p_outlier, p_lowlik=0.05, p_missing_cam=0.01)
+    eng = Engine(0)
+    try:
+        eng.set_tuning(Engine.TUNE_POOL_SINGLES_PCT, singles_pct)
+        eng.set_calibration(wl['P'])
+        prm = eng.tri_params(15.0, 0.3, 2)
+        Q, err, nex, mask = eng.triangulate(wl['xyl'], prm)
+    finally:
+        eng.close()
+    threads = min(64, len(os.sched_getaffinity(0)))
+    Qr, er, nr, mr = tri_oracle.triangulate_batch(wl['xyl'].astype(np.float64), wl['P'], None, list(range(26)), 0.3, 15.0, 2, threads=threads)
+    _compare(Q, err, nex, mask, Qr, er, nr, mr, f'C={C} outliers {p_outlier} singles {singles_pct}%')
+
+
 def test_unaligned_device_outputs(engine):
     """p2s_triangulate_device with result pointers that are only element-aligned (the packed result buffer of a
     caller need not start the float32 / uint32 / uint8 arrays on 16 bytes): same numbers as the aligned call.
