@@ -48,3 +48,13 @@ def test_geometry_query():
         assert th.value % 64 == 0 and 64 <= th.value <= 1024
         assert lds.value <= 160 * 1024
     assert lib.p2s_tri_geometry(40, 26, 0, None, None, None) != 0
+
+
+def test_tuning_constants_match_the_header():
+    """The engine's copies of the p2s_set_tuning keys and values are the header's."""
+    from pose2sim_amd.engine import Engine
+    txt = open(os.path.join(ROOT, 'include', 'p2s.h')).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define\s+P2S_((?:TUNE|TRI_PATH|ASSOC_FORM)_[A-Z_]+)\s+(\d+)', txt)}
+    assert len(defs) >= 13
+    for name, value in defs.items():
+        assert getattr(Engine, name) == value, name
