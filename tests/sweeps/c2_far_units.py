@@ -1,7 +1,7 @@
 """Diagnostics: the units of the two-camera test whose |dQ| against the C oracle exceeds 1e-7 m, with their distance
 from the origin, on both triangulation paths (is the excess a property of far, ill-posed points or of a kernel?)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import tri_oracle
 from pose2sim_amd import skeletons, synth

@@ -57,7 +57,7 @@ def _compare(Q, err, nex, mask, Qr, er, nr, mr, what=''):
         # 1e-7 m inside a 10 m capture volume, 1e-8 relative beyond it.  The relative part is needed, and only by
         # accepted garbage: with two cameras, noise can make two rays nearly parallel and the "point" lands 1.3 - 15 km
         # away with a pixel error under the threshold (units 387186, 1417924, 1484274 of the two-camera test, measured
-        # |dQ| 1.6e-7 - 7.9e-7 m = 1e-11 - 6e-10 relative, on both kernel paths alike, exp/c2_far_units.py); at that
+        # |dQ| 1.6e-7 - 7.9e-7 m = 1e-11 - 6e-10 relative, on both kernel paths alike, tests/sweeps/c2_far_units.py); at that
         # depth the reference's own SVD is no better determined.  Every unit within 100 m of the origin, on every
         # committed workload, is inside 1e-7 m unscaled (profiles/r02/sweep_tri.log: max 3.5e-9).
         scale = np.maximum(1.0, np.linalg.norm(Qr[ok], axis=1) / 10.0)
