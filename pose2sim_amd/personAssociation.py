@@ -43,21 +43,29 @@ def person_index_per_cam(affinity, cum_persons_per_view, min_cameras_for_triangu
     return proposals_from_rows(np.array(rows, dtype=float), min_cameras_for_triangulation)
 
 
-def proposals_from_rows(proposals, min_cameras_for_triangulation):
-    """Second half of person_index_per_cam (:528-549), the NumPy calls of the reference as they are: np.argsort's
-    order among equal counts is unspecified (and not stable in NumPy 2.x's SIMD sorts), so no re-implementation can
-    promise the same person order -- the same calls can."""
-    if proposals.size == 0:
+def proposals_from_rows(rows, min_cameras_for_triangulation):
+    """Second half of person_index_per_cam (:528-549).  Which proposals come first is decided by np.unique and by
+    np.argsort of their multiplicities, whose order among equal counts is unspecified (and not stable in NumPy 2.x's
+    SIMD sorts): those two calls are made exactly as the reference makes them, so the person order is the reference's.
+    What follows them is set logic: a proposal that reuses, for some camera, a person of ANY proposal before it
+    (kept or not) is dropped; so is one seen by too few cameras."""
+    if rows.size == 0:
         return np.array([])
-    proposals, nb_detections = np.unique(proposals, axis=0, return_counts=True)
-    proposals = proposals[np.argsort(nb_detections)[::-1]]
-    proposals[proposals == -1] = np.nan
-    mask = np.ones(proposals.shape[0], dtype=bool)
-    for i in range(1, len(proposals)):
-        mask[i] = ~np.any(proposals[i] == proposals[:i], axis=0).any()
-    proposals = proposals[mask]
-    nb_cams_per_person = [np.count_nonzero(~np.isnan(p)) for p in proposals]
-    return np.array([p for (n, p) in zip(nb_cams_per_person, proposals) if n >= min_cameras_for_triangulation])
+    distinct, counts = np.unique(rows, axis=0, return_counts=True)
+    ranked = distinct[np.argsort(counts)[::-1]]
+    ranked[ranked == -1] = np.nan
+    reused = np.zeros(ranked.shape, dtype=bool)
+    for cam in range(ranked.shape[1]):                      # per camera: every occurrence of a person after its first
+        col = ranked[:, cam]
+        seen = ~np.isnan(col)
+        idx = np.flatnonzero(seen)
+        _, first = np.unique(col[idx], return_index=True)
+        later = np.ones(len(idx), dtype=bool)
+        later[first] = False
+        reused[idx[later], cam] = True
+    enough = (~np.isnan(ranked)).sum(axis=1) >= min_cameras_for_triangulation
+    out = ranked[~reused.any(axis=1) & enough]
+    return out if len(out) else np.array([])
 
 
 def proposals_batch(affinity, n_persons, min_cameras_for_triangulation):
@@ -80,24 +88,9 @@ def proposals_batch(affinity, n_persons, min_cameras_for_triangulation):
 
 
 def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
-    """personAssociation.py:552-580: people reordered by proposal, {} where a camera does not see
-    the person; an unreadable source leaves no output file.  Per-frame Python form, kept as the statement the
-    native batch writer below is tested against (tests/test_rewrite_json.py); associate_all uses the batch."""
-    for cam in range(n_cams):
-        try:
-            with open(json_tracked_files_f[cam], 'w') as json_tracked_f:
-                with open(json_files_f[cam], 'r') as json_f:
-                    js = json.load(json_f)
-                    js_new = js.copy()
-                    js_new['people'] = []
-                    for new_comb in proposals:
-                        if not np.isnan(new_comb[cam]):
-                            js_new['people'] += [js['people'][int(new_comb[cam])]]
-                        else:
-                            js_new['people'] += [{}]
-                json_tracked_f.write(json.dumps(js_new))
-        except Exception:
-            os.remove(json_tracked_files_f[cam])
+    """personAssociation.py:552-580 for one frame: people reordered by proposal, {} where a camera does not see the
+    person, no output file where the source cannot be read -- one frame of the native batch writer below."""
+    rewrite_json_files_batch([list(json_tracked_files_f)[:n_cams]], [list(json_files_f)[:n_cams]], [np.asarray(proposals, dtype=float)], n_cams)
 
 
 def rewrite_json_files_batch(dst_files, src_files, proposals_per_frame, n_cams):

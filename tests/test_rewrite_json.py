@@ -32,9 +32,19 @@ EXTRA = [
 
 
 def _python_rewrite(tmp, src_files, proposals, tag):
-    dst = [os.path.join(tmp, f'py_{tag}_{c}.json') for c in range(len(src_files))]
-    pa.rewrite_json_files(dst, src_files, proposals, len(src_files))
-    return [open(d).read() if os.path.exists(d) else None for d in dst]
+    """What the reference's rewrite_json_files leaves on disk (personAssociation.py:552-580), stated with json: the
+    source document with its people replaced by one entry per proposal ({} where the camera does not see the person);
+    nothing at all when anything goes wrong (unreadable source, no 'people' list, a person index out of range)."""
+    out = []
+    for cam, src in enumerate(src_files):
+        try:
+            with open(src, 'r') as fh:
+                doc = json.load(fh)
+            picked = [{} if np.isnan(row[cam]) else doc['people'][int(row[cam])] for row in proposals]   # looked up only when needed
+            out.append(json.dumps({**doc, 'people': picked}))
+        except Exception:
+            out.append(None)
+    return out
 
 
 def test_native_rewrite_equals_json_dumps(tmp_path):
