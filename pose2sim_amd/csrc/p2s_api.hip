@@ -85,6 +85,7 @@ struct p2s_ctx {
     uint32_t max_subsets = P2S_MAX_SUBSETS_PER_LEVEL;
     int debug_mode = 0;                              // honoured by a -DP2S_DIAG build only
     int assoc_form = P2S_ASSOC_FORM_AUTO;
+    int deep_prune = 1;                              // p2s_tri_deep.hip: exact pruning of the deep levels' evaluations
     int pool_singles_pct = 8;                        // p2s_tri_fused.hip: share of the tiles that the last workgroups take one at a time
 };
 
@@ -380,6 +381,7 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
         if (value < 0) return fail(P2S_ERR_INVALID_ARG, "deep-level threshold must be >= 0");
         ctx->deep_min_subsets = (uint32_t)value;
         return P2S_OK;
+    case P2S_TUNE_DEEP_PRUNE: ctx->deep_prune = value ? 1 : 0; return P2S_OK;
     case P2S_TUNE_POOL_SINGLES_PCT:
         if (value < 0 || value > 100) return fail(P2S_ERR_INVALID_ARG, "percentage outside [0, 100]");
         ctx->pool_singles_pct = value;
@@ -525,6 +527,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         if ((rc = ctx->deep_ctl.ensure(64)) != P2S_OK) return rc;
         if ((rc = ctx->deep_sched.ensure((size_t)kDeepTickets * 2 * sizeof(uint32_t))) != P2S_OK) return rc;
         if ((rc = ctx->deep_partials.ensure((size_t)kDeepTickets * sizeof(P2sDeepPartial))) != P2S_OK) return rc;
+        dargs.prune = ctx->deep_prune ? 1u : 0u;
         dargs.entries = (unsigned char *)ctx->deep_entries.p;
         dargs.ctl = (uint32_t *)ctx->deep_ctl.p;
         dargs.sched_entry = (uint32_t *)ctx->deep_sched.p;

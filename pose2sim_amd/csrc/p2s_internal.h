@@ -29,7 +29,7 @@ struct P2sCam {
 // p2s_get_tri_stats: [0] units that entered the camera-subset search, [1] camera subsets evaluated (lane-evaluations of
 // DLT + reprojection error beyond level 0), [2] evaluation passes (64-lane), [3] units whose search was cut short by
 // P2S_MAX_SUBSETS_PER_LEVEL (they come back as not triangulated; the reference would have gone on)
-#define P2S_N_STATS 4
+#define P2S_N_STATS 6
 // the counters are kept in shards of their own 64-byte lines (a wave adds to shard blockIdx % P2S_STAT_SHARDS): one
 // word takes ~88 atomics per microsecond, and 40 000 waves adding to ONE word cost 1.2 ms per launch
 #define P2S_STAT_SHARDS 256
@@ -101,6 +101,7 @@ struct P2sDeepArgs {
     uint32_t *sched_entry, *sched_chunk;
     P2sDeepPartial *partials;
     uint32_t capacity, max_tickets, entry_bytes, obs_bytes;
+    uint32_t prune;                      // exact pruning of the evaluation (p2s_tri_deep.hip); 0: every camera of every candidate
 };
 hipError_t p2s_launch_deep_round(const struct P2sTriArgs &a, const P2sDeepArgs &d, int dtype, int grid_eval, int lds, hipStream_t s);
 

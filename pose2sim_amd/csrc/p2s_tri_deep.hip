@@ -37,6 +37,26 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Rank of the k-subset S of {0..n-1} in itertools.combinations order (the inverse of unrank_subset): the subsets
+// before it either start lower at some position, sum over x = prev+1 .. c-1 of C(n-1-x, left-1) = C(n-prev-1, left) -
+// C(n-c, left) by the hockey-stick identity.
+__device__ __forceinline__ uint32_t rank_subset(uint32_t S, int n, int k, const uint32_t *__restrict__ binom) {
+    uint32_t r = 0;
+    int prev = -1, left = k;
+    for (uint32_t b = S; b != 0u; b &= b - 1, --left) {
+        const int c = __builtin_ctz(b);
+        r += binom[(n - prev - 1) * 33 + left] - binom[(n - c) * 33 + left];
+        prev = c;
+    }
+    return r;
+}
+
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 __device__ __forceinline__ P2sDeepEntry *entry_at(const P2sDeepArgs &d, uint32_t i) {
     return reinterpret_cast<P2sDeepEntry *>(d.entries + (size_t)i * d.entry_bytes);
 }
@@ -134,6 +154,45 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
 #pragma unroll
         for (int i = 0; i < 10; ++i) oN[i] = e->N[i];
 
+        // ---- exact pruning (d.prune) --------------------------------------------------------------------------------
+        // A candidate matters only if its mean error is at most the threshold (a level that is not the unit's last and has
+        // no swap candidates: a failed level leaves nothing behind) and not above the best one seen so far.  Every term of the error sum is
+        // >= 0, so a candidate whose PARTIAL sum already exceeds bound x (cameras kept) is out -- and the partial sum
+        // grows fastest over the cameras with the largest level-0 residuals.  So: (1) the cameras are ranked by that
+        // residual once per ticket; (2) the level's subsets are enumerated over the RANKED cameras (rank r of the chunk
+        // = r-th combination of ranked positions), which puts the subsets that remove the most suspicious cameras --
+        // the only ones with a chance -- at the head of the enumeration and gives every later chunk a tight bound in
+        // whole waves of hopeless candidates; (3) the error loop runs over the ranked cameras and stops as soon as every
+        // lane of the wave is out.  A wave with a survivor re-evaluates in camera order (mean_error), so that every
+        // number that can reach the result is the one the unpruned kernel computes; ties are broken by the subset's
+        // rank in itertools order (rank_subset), which the enumeration order no longer provides.
+        __shared__ uint8_t sPermAll[4][32];
+        uint8_t *sPerm = sPermAll[wave];
+        const bool prune = d.prune != 0;
+        if (lane < 32) sPerm[lane] = (uint8_t)lane;
+        if (prune) {
+            double q0[3];
+            smallest_eigvec(oN, q0);
+            double res = -1.0;                                  // cameras that are out already go last
+            if (lane < C && ((o_valid >> lane) & 1u)) {
+                double x, y, w;
+                oobs.raw(lane, x, y, w);
+                bool reg;
+                const double dd = camera_distance<UNDISTORT>(cams + lane, q0, x, y, reg);
+                res = (dd == dd && dd >= 0.0) ? dd : -1.0;
+            }
+            int pos = 0;
+            for (int c2 = 0; c2 < C; ++c2) {
+                const double r2 = shfl_d(res, c2);
+                pos += (r2 > res || (r2 == res && c2 < lane)) ? 1 : 0;
+            }
+            wave_sync();
+            if (lane < C) sPerm[pos] = (uint8_t)lane;
+        }
+        wave_sync();
+        const bool last_level = level >= (int)e->Lmax;
+        unsigned long long st_cams = 0;                         // camera-error evaluations of plain candidates (lane level)
+
         double be = kInf, bq0 = d_nan(), bq1 = d_nan(), bq2 = d_nan();
         uint32_t brank = kNone, bS = 0;
         double se = kInf, sq0 = d_nan(), sq1 = d_nan(), sq2 = d_nan();
@@ -150,7 +209,8 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             if (LRSWAP && !skip_swap) skip_swap = __hip_atomic_load(plain_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             uint32_t S = 0;
             if (go) {
-                S = unrank_subset(r, C, level, sBinom);
+                const uint32_t Sp = unrank_subset(r, C, level, sBinom);       // over ranked positions
+                for (uint32_t b = Sp; b != 0u; b &= b - 1) S |= 1u << sPerm[__builtin_ctz(b)];
                 // duplicates of one effective configuration (quirk Q1): only the lexicographically first one -- padding =
                 // the lowest cameras of the excluded set -- can win
                 const uint32_t pad = S & o_d;
@@ -174,9 +234,35 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             double q[3];
             smallest_eigvec(Ns, q);
             if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
-            const double err = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
-            if (go && (err < be || brank == kNone)) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
-            if (LRSWAP && !skip_swap && __any(go && err <= thr)) {
+            bool alive = go;
+            if (prune) {
+                const double bw = wave_min_d(be);               // any finished candidate of the wave bounds the level's minimum
+                // with L/R-swap candidates in play the plain minimum of a FAILED level still reports its camera count
+                // when a swap candidate rescues the level (triangulation.py:576-579): only the best-so-far bounds then
+                const double bmean = (last_level || (LRSWAP && M > 2)) ? bw : fmin(bw, thr);
+                const double bnd = bmean * (double)nkept * (1.0 + 1e-9);      // inf while nothing bounds (0 x inf = NaN: never out)
+                double psum = 0.0;
+                int idx = 0;
+                for (; idx < C; ++idx) {
+                    const int c = __builtin_amdgcn_readfirstlane((int)sPerm[idx]);
+                    double x, y, w;
+                    oobs.raw(c, x, y, w);
+                    bool reg;
+                    const double dd = camera_distance<UNDISTORT>(cams + c, q, x, y, reg);
+                    psum += (((kept >> c) & 1u) && reg && dd == dd) ? dd : 0.0;   // what cannot be told here adds nothing
+                    if ((idx & 3) == 3 && __all(!go || psum > bnd)) { ++idx; break; }
+                }
+                st_cams += (unsigned long long)idx * (unsigned long long)__popcll(__ballot(go));
+                alive = go && !(psum > bnd);
+            }
+            double err = kInf;
+            if (__any(alive)) {
+                err = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
+                st_cams += (unsigned long long)C * (unsigned long long)__popcll(__ballot(go));
+            }
+            const uint32_t rt = rank_subset(S, C, level, sBinom);             // rank in itertools order: ties, reduction
+            if (alive && (brank == kNone || err < be || (err == be && rt < brank))) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
+            if (LRSWAP && !skip_swap && __any(alive && err <= thr)) {
                 skip_swap = true;
                 if (lane == 0) atomicOr(plain_ok, 1u);
             }
@@ -185,7 +271,7 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
                 // single wave knows: every chunk evaluates it, the reduction decides (triangulation.py:509)
                 double qs[3];
                 const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
-                if (go && (es < se || srank == kNone)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
+                if (go && (srank == kNone || es < se || (es == se && rt < srank))) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = rt; sS = S; }
             }
         }
         // wave argmin, lowest rank on ties (np.nanargmin / np.argmin)
@@ -206,6 +292,7 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             }
         }
         if (lane == 0) {
+            if (a.stats) atomicAdd(a.stats + 4, st_cams);
             P2sDeepPartial &p = d.partials[t];
             p.e = be; p.q[0] = bq0; p.q[1] = bq1; p.q[2] = bq2; p.rank = brank; p.S = bS;
             p.se = se; p.sq[0] = sq0; p.sq[1] = sq1; p.sq[2] = sq2; p.srank = srank; p.sS = sS;
@@ -260,7 +347,7 @@ __global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a,
         const bool more = (l_err > thr) && (level + 1 <= e->Lmax);
         const bool cont = more && (a.binom[C * 33 + level + 1] <= a.max_subsets);
         if (more && !cont && a.stats) atomicAdd(a.stats + 3, 1ull);                  // stopped by the safety valve
-        if (a.stats) { atomicAdd(a.stats + 1, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 2, (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64)); }
+        if (a.stats) { atomicAdd(a.stats + 1, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 5, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 2, (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64)); }
         if (cont) {
             e->level = (uint32_t)(level + 1);
             e->state = P2S_DEEP_WAITING;

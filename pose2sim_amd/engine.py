@@ -89,16 +89,17 @@ class Engine:
 
     # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
     TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS, TUNE_DEEP_MIN_SUBSETS = 1, 2, 3, 4, 5, 6, 7
-    TUNE_ASSOC_FORM, TUNE_POOL_SINGLES_PCT = 8, 9
+    TUNE_ASSOC_FORM, TUNE_POOL_SINGLES_PCT, TUNE_DEEP_PRUNE = 8, 9, 10
     TRI_PATH_AUTO, TRI_PATH_WORKLIST, TRI_PATH_ONE_TILE = 0, 1, 2
     ASSOC_FORM_AUTO, ASSOC_FORM_GENERAL = 0, 1
 
     def tri_stats(self, reset=False):
         """Counters of this engine's triangulation calls: units that entered the camera-subset search, subsets
         evaluated, 64-lane evaluation passes, units stopped by the 2^26-subsets-per-level safety valve."""
-        out = np.zeros(4, dtype=np.uint64)
+        out = np.zeros(6, dtype=np.uint64)
         _lib.check(self._lib.p2s_get_tri_stats(self._h, _ptr(out), 1 if reset else 0))
-        return {'search_units': int(out[0]), 'subsets_evaluated': int(out[1]), 'passes': int(out[2]), 'capped_units': int(out[3])}
+        return {'search_units': int(out[0]), 'subsets_evaluated': int(out[1]), 'passes': int(out[2]), 'capped_units': int(out[3]),
+                'deep_camera_errors': int(out[4]), 'deep_subsets': int(out[5])}
 
     def assoc_stats(self, reset=False):
         """Counters of this engine's multi-person association calls: frames with detections, ADMM passes, Jacobi sweeps,
