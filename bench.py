@@ -353,10 +353,10 @@ def fp64_flops_per_step(n_units, C, stats_per_step):
     level0 = n_units * (C * (FLOP_ACC_PER_CAM + FLOP_ERR_PER_CAM) + FLOP_EIGEN)
     # a subset evaluation: downdate of the removed cameras (1.2 on average over the levels that occur), eigen-solve,
     # error over all C cameras (masked)
-    # the deep-level rounds drop hopeless candidates after a few cameras: their error work is counted by the kernel
-    deep = stats_per_step.get('deep_subsets', 0.0)
+    # the long levels drop hopeless candidates after a few cameras: their error work is counted by the kernels
+    deep = stats_per_step.get('pruned_subsets', 0.0)
     evals = (stats_per_step['subsets_evaluated'] - deep) * (1.2 * FLOP_ACC_PER_CAM + FLOP_EIGEN + C * FLOP_ERR_PER_CAM)
-    evals += deep * (1.2 * FLOP_ACC_PER_CAM + FLOP_EIGEN) + stats_per_step.get('deep_camera_errors', 0.0) * FLOP_ERR_PER_CAM
+    evals += deep * (1.2 * FLOP_ACC_PER_CAM + FLOP_EIGEN) + stats_per_step.get('pruned_camera_errors', 0.0) * FLOP_ERR_PER_CAM
     return level0 + evals
 
 

@@ -185,8 +185,9 @@ int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, cons
  * first pass), out[1] camera subsets evaluated, out[2] 64-lane evaluation passes, out[3] units whose search stopped at
  * the safety valve (a level with more than 2^26 subsets, i.e. C(32, 11) and beyond, is not entered: such a unit comes
  * back as not triangulated where the reference would have gone on for hours -- callers report the count), out[4]
- * per-camera reprojection errors computed for the candidates of the deep-level rounds (fewer than cameras x subsets:
- * hopeless candidates are dropped after a few cameras), out[5] the part of out[1] that the deep-level rounds evaluated. */
+ * per-camera reprojection errors computed for the candidates of the pruned passes (levels of hundreds of subsets and
+ * more: hopeless candidates are dropped after a few cameras, so fewer than cameras x subsets), out[5] those candidates
+ * (a part of out[1]). */
 int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 
 /* Counters of the multi-person association calls of this context since creation (or the last reset), after
@@ -212,8 +213,8 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
  *                         2^26; this one DOES change results -- tests of the valve only)
  *   P2S_TUNE_DEEP_MIN_SUBSETS  levels of the work-list search with more camera subsets than this (default 16 384) are
  *                         cut into chunks and spread over the whole GPU instead of being walked by one wave; 0 = never
- *   P2S_TUNE_DEEP_PRUNE   0: the deep-level rounds evaluate every camera of every candidate (default 1: exact pruning,
- *                         same results)
+ *   P2S_TUNE_DEEP_PRUNE   0: the long levels evaluate every camera of every candidate (default 1: exact pruning, same
+ *                         results)
  *   P2S_TUNE_ASSOC_FORM   P2S_ASSOC_FORM_AUTO (default): up to 32 detections per frame take the symmetric one-wave kernel;
  *                         P2S_ASSOC_FORM_GENERAL: the general kernel (no symmetry assumed) at every size
  *   P2S_TUNE_DIAG_MODE    kernel diagnostics of a -DP2S_DIAG build (exp/README.md); refused by the shipped library */

@@ -506,6 +506,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
     a.thr = params->reproj_error_threshold;
     a.lik_thr = params->likelihood_threshold;
     a.debug_mode = ctx->debug_mode;                                   // 0 unless a -DP2S_DIAG build was told otherwise
+    a.prune = ctx->deep_prune;
 
     // Deep levels: can a level of this camera count exceed the threshold at all?  Then units about to enter one are
     // exported by the search kernel and finished by rounds of plan / eval / reduce over the whole GPU, chunk by chunk

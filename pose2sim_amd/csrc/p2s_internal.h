@@ -28,7 +28,8 @@ struct P2sCam {
 
 // p2s_get_tri_stats: [0] units that entered the camera-subset search, [1] camera subsets evaluated (lane-evaluations of
 // DLT + reprojection error beyond level 0), [2] evaluation passes (64-lane), [3] units whose search was cut short by
-// P2S_MAX_SUBSETS_PER_LEVEL (they come back as not triangulated; the reference would have gone on)
+// P2S_MAX_SUBSETS_PER_LEVEL (they come back as not triangulated; the reference would have gone on), [4] per-camera errors
+// computed for the candidates of the pruned passes, [5] those candidates (a part of [1])
 #define P2S_N_STATS 6
 // the counters are kept in shards of their own 64-byte lines (a wave adds to shard blockIdx % P2S_STAT_SHARDS): one
 // word takes ~88 atomics per microsecond, and 40 000 waves adding to ONE word cost 1.2 ms per launch
@@ -67,6 +68,7 @@ struct P2sTriArgs {
     uint32_t deep_capacity, deep_entry_bytes, deep_min_subsets;
     uint32_t max_subsets;        // search kernel: a level with more subsets is not entered (P2S_MAX_SUBSETS_PER_LEVEL unless tuned)
     uint32_t pool_pairs, pool_singles;   // p2s_tri_fused.hip: per XCD, workgroups that take two tiles, then workgroups that take one
+    int32_t prune;               // exact pruning of the subset evaluations where a wave works on one unit (search kernel, deep rounds)
     int32_t job;                 // work-list records a search wave takes at a time (<= 64); sizes its LDS region
     int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
     double thr, lik_thr;

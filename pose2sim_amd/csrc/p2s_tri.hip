@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
     uint32_t n_jobs = 0;
     if (trace) t_begin = __builtin_amdgcn_s_memrealtime();
     uint32_t st_units = 0, st_evals = 0, st_passes = 0, st_capped = 0;     // p2s_get_tri_stats (wave-uniform counts)
+    unsigned long long st_pcams = 0, st_psubs = 0;                          // candidates of the pruned passes, and their camera errors
     for (;;) {
         uint64_t t0 = 0;
         if (trace) t0 = __builtin_amdgcn_s_memtime();
@@ -537,12 +538,53 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 double se = kInf, sq0 = d_nan(), sq1 = d_nan(), sq2 = d_nan();
                 uint32_t srank = 0xffffffffu, sS = 0;
 
+                // Exact pruning where the whole wave works on ONE unit (64 lanes per unit: the levels of hundreds of
+                // subsets and more), as in the deep rounds (p2s_tri_deep.hip): cameras ranked by their level-0 residual,
+                // the level's subsets enumerated over the ranked cameras, the error loop over the ranked cameras until
+                // every lane of the wave is out; a wave with a survivor re-evaluates in camera order; ties by the rank
+                // in itertools order.
+                __shared__ uint8_t sPermAll[4][32];
+                uint8_t *sPerm = sPermAll[(threadIdx.x >> 6) & 3];
+                const bool pr64 = a.prune && G == 64 && owner >= 0;
+                // no further level will replace this one's result: the unit's last level, or the next one is behind the valve
+                const bool last_level = level >= __shfl(Lmax, src, 64) || sBinom[C * 33 + level + 1] > a.max_subsets;
+                if (pr64) {
+                    double Nf[10], q0[3];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) Nf[i] = oN[i];
+                    smallest_eigvec(Nf, q0);
+                    double res = -1.0;                              // cameras that are out already go last
+                    if (lane < C && ((o_valid >> lane) & 1u)) {
+                        double x, y, w;
+                        oobs.raw(lane, x, y, w);
+                        bool reg;
+                        const double dd = camera_distance<UNDISTORT>(cams + lane, q0, x, y, reg);
+                        res = (dd == dd && dd >= 0.0) ? dd : -1.0;
+                    }
+                    int pos = 0;
+                    for (int c2 = 0; c2 < C; ++c2) {
+                        const double r2 = shfl_d(res, c2);
+                        pos += (r2 > res || (r2 == res && c2 < lane)) ? 1 : 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < C) sPerm[pos] = (uint8_t)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+
                 for (uint32_t r0 = 0; r0 < nsub; r0 += G) {
                     const uint32_t r = r0 + lig;
                     bool go = (owner >= 0) && (r < nsub);
                     uint32_t S = 0;
                     if (go) {
                         S = unrank_subset(r, C, level, sBinom);
+                        if (pr64) {                                 // r counts combinations of ranked positions
+                            uint32_t Sm = 0;
+                            for (uint32_t b = S; b != 0u; b &= b - 1) Sm |= 1u << sPerm[__builtin_ctz(b)];
+                            S = Sm;
+                        }
                         // duplicates of one effective configuration (quirk Q1) carry identical numbers;
                         // only the lexicographically first one -- padding = lowest cameras of D -- can win
                         const uint32_t pad = S & o_d;
@@ -569,8 +611,34 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                     double q[3];
                     smallest_eigvec(Ns, q);
                     if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
-                    const double e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
-                    if (go && (e < be || brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
+                    if (pr64) {
+                        const double bw = wave_min_d(be);           // any finished candidate bounds the level's minimum
+                        // with swap candidates in play the plain minimum of a FAILED level still reports its camera count
+                        // when a swap candidate rescues the level (:576-579): only the best-so-far bounds then
+                        const double bmean = (last_level || (LRSWAP && M > 2)) ? bw : fmin(bw, thr);
+                        const double bnd = bmean * (double)nkept * (1.0 + 1e-9);
+                        double psum = 0.0;
+                        int idx = 0;
+                        for (; idx < C; ++idx) {
+                            const int c = __builtin_amdgcn_readfirstlane((int)sPerm[idx]);
+                            double x, y, w;
+                            oobs.raw(c, x, y, w);
+                            bool reg;
+                            const double dd = camera_distance<UNDISTORT>(cams + c, q, x, y, reg);
+                            psum += (((kept >> c) & 1u) && reg && dd == dd) ? dd : 0.0;
+                            if ((idx & 3) == 3 && __all(!go || psum > bnd)) { ++idx; break; }
+                        }
+                        const unsigned long long ngo = (unsigned long long)__popcll(__ballot(go));
+                        st_pcams += (unsigned long long)idx * ngo; st_psubs += ngo;
+                        const bool alive = go && !(psum > bnd);
+                        double e = kInf;
+                        if (__any(alive)) { e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q); st_pcams += (unsigned long long)C * ngo; }
+                        const uint32_t rt = rank_subset(S, C, level, sBinom);
+                        if (alive && (brank == 0xffffffffu || e < be || (e == be && rt < brank))) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
+                    } else {
+                        const double e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
+                        if (go && (e < be || brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
+                    }
                 }
 
                 // group argmin, first (lowest-rank) index on ties (np.nanargmin, :502; np.argmin, :568)
@@ -688,6 +756,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
         atomicAdd(st + 1, (unsigned long long)st_evals);
         atomicAdd(st + 2, (unsigned long long)st_passes);
         if (st_capped) atomicAdd(st + 3, (unsigned long long)st_capped);
+        if (st_psubs) { atomicAdd(st + 4, st_pcams); atomicAdd(st + 5, st_psubs); }
     }
     if (trace && lane == 0) {
         double *o = a.Q + (size_t)gwave * 8;

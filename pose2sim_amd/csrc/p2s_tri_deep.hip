@@ -37,26 +37,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Rank of the k-subset S of {0..n-1} in itertools.combinations order (the inverse of unrank_subset): the subsets
-// before it either start lower at some position, sum over x = prev+1 .. c-1 of C(n-1-x, left-1) = C(n-prev-1, left) -
-// C(n-c, left) by the hockey-stick identity.
-__device__ __forceinline__ uint32_t rank_subset(uint32_t S, int n, int k, const uint32_t *__restrict__ binom) {
-    uint32_t r = 0;
-    int prev = -1, left = k;
-    for (uint32_t b = S; b != 0u; b &= b - 1, --left) {
-        const int c = __builtin_ctz(b);
-        r += binom[(n - prev - 1) * 33 + left] - binom[(n - c) * 33 + left];
-        prev = c;
-    }
-    return r;
-}
-
-__device__ __forceinline__ double wave_min_d(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
 __device__ __forceinline__ P2sDeepEntry *entry_at(const P2sDeepArgs &d, uint32_t i) {
     return reinterpret_cast<P2sDeepEntry *>(d.entries + (size_t)i * d.entry_bytes);
 }
@@ -190,7 +170,8 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             if (lane < C) sPerm[pos] = (uint8_t)lane;
         }
         wave_sync();
-        const bool last_level = level >= (int)e->Lmax;
+        // no further level will replace this one's result: the unit's last level, or the next one is behind the valve
+        const bool last_level = level >= (int)e->Lmax || sBinom[C * 33 + level + 1] > a.max_subsets;
         unsigned long long st_cams = 0;                         // camera-error evaluations of plain candidates (lane level)
 
         double be = kInf, bq0 = d_nan(), bq1 = d_nan(), bq2 = d_nan();
@@ -292,7 +273,7 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             }
         }
         if (lane == 0) {
-            if (a.stats) atomicAdd(a.stats + 4, st_cams);
+            if (a.stats && prune) atomicAdd(a.stats + 4, st_cams);
             P2sDeepPartial &p = d.partials[t];
             p.e = be; p.q[0] = bq0; p.q[1] = bq1; p.q[2] = bq2; p.rank = brank; p.S = bS;
             p.se = se; p.sq[0] = sq0; p.sq[1] = sq1; p.sq[2] = sq2; p.srank = srank; p.sS = sS;
@@ -347,7 +328,7 @@ __global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a,
         const bool more = (l_err > thr) && (level + 1 <= e->Lmax);
         const bool cont = more && (a.binom[C * 33 + level + 1] <= a.max_subsets);
         if (more && !cont && a.stats) atomicAdd(a.stats + 3, 1ull);                  // stopped by the safety valve
-        if (a.stats) { atomicAdd(a.stats + 1, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 5, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 2, (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64)); }
+        if (a.stats) { atomicAdd(a.stats + 1, (unsigned long long)a.binom[C * 33 + level]); if (d.prune) atomicAdd(a.stats + 5, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 2, (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64)); }
         if (cont) {
             e->level = (uint32_t)(level + 1);
             e->state = P2S_DEEP_WAITING;

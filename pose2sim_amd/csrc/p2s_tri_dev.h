@@ -284,6 +284,26 @@ __device__ __forceinline__ uint32_t unrank_subset(uint32_t r, int n, int k, cons
     return S;
 }
 
+// Rank of the k-subset S of {0..n-1} in itertools.combinations order (the inverse of unrank_subset): the subsets
+// before it either start lower at some position, sum over x = prev+1 .. c-1 of C(n-1-x, left-1) = C(n-prev-1, left) -
+// C(n-c, left) by the hockey-stick identity.
+__device__ __forceinline__ uint32_t rank_subset(uint32_t S, int n, int k, const uint32_t *__restrict__ binom) {
+    uint32_t r = 0;
+    int prev = -1, left = k;
+    for (uint32_t b = S; b != 0u; b &= b - 1, --left) {
+        const int c = __builtin_ctz(b);
+        r += binom[(n - prev - 1) * 33 + left] - binom[(n - c) * 33 + left];
+        prev = c;
+    }
+    return r;
+}
+
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
 // Index of the n-th (0-based) set bit of a 64-bit mask, or -1.
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
     for (int i = 0; i < n; ++i) m &= m - 1;

@@ -99,7 +99,7 @@ class Engine:
         out = np.zeros(6, dtype=np.uint64)
         _lib.check(self._lib.p2s_get_tri_stats(self._h, _ptr(out), 1 if reset else 0))
         return {'search_units': int(out[0]), 'subsets_evaluated': int(out[1]), 'passes': int(out[2]), 'capped_units': int(out[3]),
-                'deep_camera_errors': int(out[4]), 'deep_subsets': int(out[5])}
+                'pruned_camera_errors': int(out[4]), 'pruned_subsets': int(out[5])}
 
     def assoc_stats(self, reset=False):
         """Counters of this engine's multi-person association calls: frames with detections, ADMM passes, Jacobi sweeps,

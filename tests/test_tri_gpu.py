@@ -335,6 +335,40 @@ def test_pooled_search_slots_and_tile_pairing(C, p_outlier, F, singles_pct):
     _compare(Q, err, nex, mask, Qr, er, nr, mr, f'C={C} outliers {p_outlier} singles {singles_pct}%')
 
 
+@pytest.mark.parametrize('C,min_cams,lr_swap,undistort,deep_min', [(32, 24, False, False, 16384), (32, 25, True, True, 16384),
+                                                                   (24, 18, True, False, 100), (20, 14, False, True, 100), (12, 3, False, False, 10)])
+def test_exact_pruning_changes_nothing(C, min_cams, lr_swap, undistort, deep_min):
+    """The long levels (64 lanes per unit in the search kernel, and the deep rounds) drop candidates whose partial error
+    sum over the most suspicious cameras already exceeds what can still matter: the outputs are bit for bit those of
+    the run that evaluates every camera of every candidate, and the counters show that cameras were in fact skipped."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from pose2sim_amd import skeletons, synth
+    from pose2sim_amd.engine import Engine
+    _, _, swap = skeletons.keypoints('HALPE_26')
+    wl = synth.make_config(300, C, 26, 1, seed=700 + C, undistort=undistort, lr_swap=lr_swap, swap_idx=swap,
+                           p_outlier=0.12, p_lowlik=0.04, p_missing_cam=0.02)
+    eng = Engine(0)
+    try:
+        eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_WORKLIST)
+        eng.set_tuning(Engine.TUNE_DEEP_MIN_SUBSETS, deep_min)
+        eng.set_calibration(wl['P'], wl['cams'] if undistort else None)
+        prm = eng.tri_params(6.0, 0.3, min_cams, undistort, lr_swap)
+        eng.set_tuning(Engine.TUNE_DEEP_PRUNE, 0)
+        ref = eng.triangulate(wl['xyl'], prm, swap if lr_swap else None)
+        st0 = eng.tri_stats(reset=True)
+        eng.set_tuning(Engine.TUNE_DEEP_PRUNE, 1)
+        got = eng.triangulate(wl['xyl'], prm, swap if lr_swap else None)
+        st1 = eng.tri_stats(reset=True)
+    finally:
+        eng.close()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert st0['pruned_subsets'] == 0 and st0['subsets_evaluated'] == st1['subsets_evaluated']
+    assert st1['pruned_subsets'] > 0
+    assert st1['pruned_camera_errors'] < C * st1['pruned_subsets']           # cameras were skipped
+
+
 def test_unaligned_device_outputs(engine):
     """p2s_triangulate_device with result pointers that are only element-aligned (the packed result buffer of a
     caller need not start the float32 / uint32 / uint8 arrays on 16 bytes): same numbers as the aligned call.
