@@ -662,6 +662,11 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                             uint32_t S = 0;
                             if (go) {
                                 S = unrank_subset(r, C, level, sBinom);
+                                if (pr64) {                         // over the ranked cameras, as the plain candidates
+                                    uint32_t Sm = 0;
+                                    for (uint32_t b = S; b != 0u; b &= b - 1) Sm |= 1u << sPerm[__builtin_ctz(b)];
+                                    S = Sm;
+                                }
                                 const uint32_t pad = S & o_d;
                                 const int np = __popc(pad);
                                 uint32_t low = 0, dd = o_d;
@@ -671,8 +676,16 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                             if (!__any(go)) continue;
                             const uint32_t kept = o_valid & ~(S & o_valid);
                             double qs[3];
-                            const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
-                            if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
+                            if (pr64) {
+                                swap_solve<T, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                                const double sw = wave_min_d(se);
+                                const double es = swap_error_pruned<T, UNDISTORT>(cams, C, oobs_sw, kept, M, qs, sPerm, go, last_level ? sw : fmin(sw, thr));
+                                const uint32_t rt = rank_subset(S, C, level, sBinom);
+                                if (go && (srank == 0xffffffffu || es < se || (es == se && rt < srank))) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = rt; sS = S; }
+                            } else {
+                                const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                                if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
+                            }
                         }
                         for (int off = G >> 1; off > 0; off >>= 1) {
                             const double xe = shfl_d(se, lane ^ off);

@@ -251,7 +251,16 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
                 // the swap candidate counts only if the level's plain minimum stays above the threshold, which no
                 // single wave knows: every chunk evaluates it, the reduction decides (triangulation.py:509)
                 double qs[3];
-                const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                swap_solve<T, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                double es;
+                if (prune) {
+                    // a swap candidate counts only under the threshold unless this is the last level (:576-579); the
+                    // cameras that disagree with the majority are the suspicious ones for the mirrored point as well
+                    const double sw = wave_min_d(se);
+                    es = swap_error_pruned<T, UNDISTORT>(cams, C, oobs_sw, kept, M, qs, sPerm, go, last_level ? sw : fmin(sw, thr));
+                } else {
+                    es = swap_error<T, UNDISTORT, 0>(cams, C, oobs_sw, kept, M, qs);
+                }
                 if (go && (srank == kNone || es < se || (es == se && rt < srank))) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = rt; sS = S; }
             }
         }

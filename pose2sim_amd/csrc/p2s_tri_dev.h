@@ -455,10 +455,9 @@ __device__ __forceinline__ double mean_error(cam_cptr cams, int C, const OBS &o,
 
 // L/R-swap candidate (triangulation.py:509-561, quirk Q3): the first M kept cameras carry the
 // mirrored keypoint's (x, y), still weighted by the unit's own likelihoods; the error is the mean
-// over those first M cameras only.
-template <typename T, bool UNDISTORT, int CT = 0, typename OBS>
-__device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const OBS &o, const OBS &osw, uint32_t kept,
-                                                 int M, double qs[3]) {
+// over those first M cameras only.  In two parts, so that a caller may look at a few cameras first.
+template <typename T, int CT = 0, typename OBS>
+__device__ __forceinline__ void swap_solve(cam_cptr cams, int C, const OBS &o, const OBS &osw, uint32_t kept, int M, double qs[3]) {
     double Nw[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) Nw[i] = 0.0;
@@ -473,9 +472,13 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const OBS
         taken += k ? 1 : 0;
     });
     smallest_eigvec(Nw, qs);
+}
+
+template <typename T, bool UNDISTORT, int CT = 0, typename OBS>
+__device__ __forceinline__ double swap_error(cam_cptr cams, int C, const OBS &osw, uint32_t kept, int M, const double qs[3]) {
     double sum = 0.0;
     bool irregular = false;
-    taken = 0;
+    int taken = 0;
     for_each_cam<CT>(C, [&](int c) {
         double xs, ys;
         osw.masked_xy(c, xs, ys);
@@ -502,6 +505,37 @@ __device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const OBS
     return sum * fast_rcp((double)M);
 }
 
+template <typename T, bool UNDISTORT, int CT = 0, typename OBS>
+__device__ __forceinline__ double swap_candidate(cam_cptr cams, int C, const OBS &o, const OBS &osw, uint32_t kept,
+                                                 int M, double qs[3]) {
+    swap_solve<T, CT>(cams, C, o, osw, kept, M, qs);
+    return swap_error<T, UNDISTORT, CT>(cams, C, osw, kept, M, qs);
+}
+
+// A swap candidate whose error is certainly above `bmean` is worth nothing (bmean: what can still matter; the sum of the
+// first-M kept cameras' distances only grows): the distances of the cameras in `order` (most suspicious first, wave
+// uniform) are added until every lane of the wave is out -- then inf comes back -- or all are through, in which case
+// the candidate is evaluated as swap_error does it.  NaN terms add nothing here and bound nothing.
+template <typename T, bool UNDISTORT, typename OBS>
+__device__ __forceinline__ double swap_error_pruned(cam_cptr cams, int C, const OBS &osw, uint32_t kept, int M, const double qs[3],
+                                                    const uint8_t *order, bool go, double bmean) {
+    const double bnd = bmean * (double)M * (1.0 + 1e-9);
+    double psum = 0.0;
+    for (int idx = 0; idx < C; ++idx) {
+        const int c = __builtin_amdgcn_readfirstlane((int)order[idx]);
+        double xs, ys;
+        osw.masked_xy(c, xs, ys);
+        bool reg;
+        const double d = camera_distance<UNDISTORT>(cams + c, qs, xs, ys, reg);
+        const bool k = ((kept >> c) & 1u) && (__popc(kept & ((1u << c) - 1u)) < M);     // among the first M kept cameras
+        psum += (k && reg && d == d) ? d : 0.0;
+        if ((idx & 3) == 3 && __all(!go || psum > bnd)) break;
+    }
+    const bool alive = go && !(psum > bnd);
+    if (!__any(alive)) return kInf;
+    const double es = swap_error<T, UNDISTORT, 0>(cams, C, osw, kept, M, qs);
+    return alive ? es : kInf;
+}
 
 }  // namespace
 
