@@ -432,7 +432,7 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         a.xyl = d_xyl;
         a.Q = d_Q; a.err = d_err; a.n_excl = d_n_excl; a.mask = d_excl_mask;
         a.cams = ctx->d_cams;
-        a.sub_tab = ctx->d_sub_tab; a.sub_off = ctx->d_sub_off;
+        a.sub_tab = ctx->d_sub_tab; a.sub_off = ctx->d_sub_off; a.binom = ctx->d_binom;
         a.stats = ctx->d_stats;
         a.K = n_kpts; a.C = C;
         a.min_cams = params->min_cameras;
