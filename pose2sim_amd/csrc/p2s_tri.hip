@@ -656,6 +656,9 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 if (LRSWAP) {
                     const bool need_sw = (owner >= 0) && (M > 2) && (be > thr);
                     if (__any(need_sw)) {
+                        double Nsw[10];
+                        uint32_t nan_sw = 0;
+                        swap_base<T>(cams, C, oobs, oobs_sw, o_valid, Nsw, nan_sw);   // all valid cameras mirrored, once per pass
                         for (uint32_t r0 = 0; r0 < nsub; r0 += G) {
                             const uint32_t r = r0 + lig;
                             bool go = need_sw && (r < nsub);
@@ -676,14 +679,14 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                             if (!__any(go)) continue;
                             const uint32_t kept = o_valid & ~(S & o_valid);
                             double qs[3];
+                            swap_solve_from_base<T>(Nsw, nan_sw, sP, oobs, oobs_sw, o_valid, kept, M, go, qs);
                             if (pr64) {
-                                swap_solve<T, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
                                 const double sw = wave_min_d(se);
                                 const double es = swap_error_pruned<T, UNDISTORT>(cams, C, oobs_sw, kept, M, qs, sPerm, go, last_level ? sw : fmin(sw, thr));
                                 const uint32_t rt = rank_subset(S, C, level, sBinom);
                                 if (go && (srank == 0xffffffffu || es < se || (es == se && rt < srank))) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = rt; sS = S; }
                             } else {
-                                const double es = swap_candidate<T, UNDISTORT, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                                const double es = swap_error<T, UNDISTORT, 0>(cams, C, oobs_sw, kept, M, qs);
                                 if (go && (es < se || srank == 0xffffffffu)) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = r; sS = S; }
                             }
                         }

@@ -171,6 +171,9 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
         }
         wave_sync();
         // no further level will replace this one's result: the unit's last level, or the next one is behind the valve
+        double Nsw[10];
+        uint32_t nan_sw = 0;
+        if (LRSWAP && M > 2) swap_base<T>(cams, C, oobs, oobs_sw, o_valid, Nsw, nan_sw);   // all valid cameras mirrored, once per ticket
         const bool last_level = level >= (int)e->Lmax || sBinom[C * 33 + level + 1] > a.max_subsets;
         unsigned long long st_cams = 0;                         // camera-error evaluations of plain candidates (lane level)
 
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
                 // the swap candidate counts only if the level's plain minimum stays above the threshold, which no
                 // single wave knows: every chunk evaluates it, the reduction decides (triangulation.py:509)
                 double qs[3];
-                swap_solve<T, 0>(cams, C, oobs, oobs_sw, kept, M, qs);
+                swap_solve_from_base<T>(Nsw, nan_sw, sP, oobs, oobs_sw, o_valid, kept, M, go, qs);
                 double es;
                 if (prune) {
                     // a swap candidate counts only under the threshold unless this is the last level (:576-579); the

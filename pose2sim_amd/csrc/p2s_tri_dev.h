@@ -474,6 +474,65 @@ __device__ __forceinline__ void swap_solve(cam_cptr cams, int C, const OBS &o, c
     smallest_eigvec(Nw, qs);
 }
 
+// The same solve for the many candidates of one unit's level: the normal matrix of ALL valid cameras with the mirrored
+// coordinates is built once (swap_base; cameras whose mirrored point is masked are left out and remembered), and a
+// candidate subtracts the cameras it removes -- and, where the subset "removes" cameras that were out already (quirk Q1
+// padding), the last kept cameras, which then keep their own coordinates (only the first M kept ones are mirrored), and
+// adds those back with their own coordinates.  A mirrored camera with a masked point makes the whole candidate NaN, as
+// its row does in the accumulation above.  P comes from LDS (per-lane camera indices).
+template <typename T, typename OBS>
+__device__ __forceinline__ void swap_base(cam_cptr cams, int C, const OBS &o, const OBS &osw, uint32_t valid, double Nsw[10],
+                                          uint32_t &nan_sw) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Nsw[i] = 0.0;
+    nan_sw = 0;
+    for_each_cam<0>(C, [&](int c) {
+        double x, y, w, xs, ys;
+        o.raw(c, x, y, w);
+        osw.masked_xy(c, xs, ys);
+        const bool v = (valid >> c) & 1u;
+        const bool bad = v && (!(xs == xs) || !(ys == ys));
+        nan_sw |= bad ? (1u << c) : 0u;
+        const bool use = v && !bad;
+        accum_camera<1>(Nsw, cams[c].P, use ? xs : 0.0, use ? ys : 0.0, use ? w : 0.0);
+    });
+}
+
+template <typename T, typename OBS>
+__device__ __forceinline__ void swap_solve_from_base(const double Nsw[10], uint32_t nan_sw, const double *sP, const OBS &o,
+                                                     const OBS &osw, uint32_t valid, uint32_t kept, int M, bool go, double qs[3]) {
+    double Ns[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) Ns[i] = Nsw[i];
+    uint32_t tail = 0;                                          // kept cameras beyond the first M: their own coordinates
+    {
+        uint32_t k = kept;
+        for (int extra = go ? __popc(kept) - M : 0; __any(extra > 0); --extra) {
+            const bool on = extra > 0 && k != 0u;
+            const int c = on ? 31 - __builtin_clz(k) : 0;
+            tail |= on ? (1u << c) : 0u;
+            k &= on ? ~(1u << c) : ~0u;
+        }
+    }
+    for (uint32_t rr = go ? (((valid & ~kept) | tail) & ~nan_sw) : 0u; __any(rr != 0u); rr &= rr - 1) {
+        const bool on = rr != 0u;
+        const int c = on ? __builtin_ctz(rr) : 0;
+        double x, y, w, xs, ys;
+        o.raw(c, x, y, w);
+        osw.masked_xy(c, xs, ys);
+        accum_camera<-1>(Ns, sP + c * 12, on ? xs : 0.0, on ? ys : 0.0, on ? w : 0.0);
+    }
+    for (uint32_t rr = go ? tail : 0u; __any(rr != 0u); rr &= rr - 1) {
+        const bool on = rr != 0u;
+        const int c = on ? __builtin_ctz(rr) : 0;
+        double x, y, w;
+        o.raw(c, x, y, w);
+        accum_camera<1>(Ns, sP + c * 12, on ? x : 0.0, on ? y : 0.0, on ? w : 0.0);
+    }
+    smallest_eigvec(Ns, qs);
+    if ((kept & ~tail & nan_sw) != 0u) { qs[0] = d_nan(); qs[1] = d_nan(); qs[2] = d_nan(); }
+}
+
 template <typename T, bool UNDISTORT, int CT = 0, typename OBS>
 __device__ __forceinline__ double swap_error(cam_cptr cams, int C, const OBS &osw, uint32_t kept, int M, const double qs[3]) {
     double sum = 0.0;
