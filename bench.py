@@ -360,6 +360,42 @@ def fp64_flops_per_step(n_units, C, stats_per_step):
     return level0 + evals
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run N ranks as children through torch.distributed.run (one per GPU,
+    rendezvous on 127.0.0.1 at a free port) and return their exit code.  The parent imports neither torch nor the
+    engine: a process that has initialised the GPU must never be replaced or forked into ranks."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """P2S_BENCH_DRY=1 (tests/test_bench_launch.py, no GPU): every rank joins a gloo group, the ranks are counted with
+    one all-reduce and rank 0 prints a JSON line -- the launch path of `--gpus N` without the engine."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        dist.init_process_group('gloo')
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'ranks_seen': seen, 'steps': args.steps, 'config': args.config}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -372,8 +408,20 @@ def main():
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as a plain `python bench.py --gpus N`: this process becomes the launcher (it has not touched the GPU
+        # and never will) and the N ranks are fresh child processes; rank 0's JSON line goes to our stdout
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world_env}: start one rank per GPU '
+                         f'(python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 '
+                         f'bench.py --gpus {args.gpus} ...) or run plain `python bench.py --gpus {args.gpus}`, which does that itself')
+    if os.environ.get('P2S_BENCH_DRY') == '1':
+        return dry_run(args)
     cfg0 = CONFIGS[args.config]
     cpu = None
     if not args.no_cpu_baseline and world_env == 1 and not (cfg0.get('assoc') or cfg0.get('single')):
@@ -390,9 +438,7 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    world = world_env
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
     # rehearsal on a one-GPU box: P2S_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo

@@ -17,7 +17,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL_Q = 1e-7        # metres
+TOL_Q = 1e-7        # metres, absolute, for every unit within FAR_M of the origin
+TOL_Q_REL = 1e-9    # relative to |Q| beyond FAR_M (two-camera units that land kilometres away)
+FAR_M = 100.0
 TOL_E = 2e-6        # px, relative to max(1, err)
 
 
@@ -54,15 +56,23 @@ def _compare(Q, err, nex, mask, Qr, er, nr, mr, what=''):
     ok = ~np.isnan(er)
     assert np.isnan(Q[~ok]).all()
     if ok.any():
-        # 1e-7 m inside a 10 m capture volume, 1e-8 relative beyond it.  The relative part is needed, and only by
-        # accepted garbage: with two cameras, noise can make two rays nearly parallel and the "point" lands 1.3 - 15 km
-        # away with a pixel error under the threshold (units 387186, 1417924, 1484274 of the two-camera test, measured
-        # |dQ| 1.6e-7 - 7.9e-7 m = 1e-11 - 6e-10 relative, on both kernel paths alike, tests/sweeps/c2_far_units.py); at that
-        # depth the reference's own SVD is no better determined.  Every unit within 100 m of the origin, on every
-        # committed workload, is inside 1e-7 m unscaled (profiles/r02/sweep_tri.log: max 3.5e-9).
-        scale = np.maximum(1.0, np.linalg.norm(Qr[ok], axis=1) / 10.0)
-        dq = (np.abs(Q[ok] - Qr[ok]).max(axis=1) / scale).max()
-        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m (relative to max(10 m, |Q|) / 10 m)'
+        # 1e-7 m ABSOLUTE for every unit within 100 m of the origin; 1e-9 relative beyond.  The relative part is needed,
+        # and only by accepted garbage: with two cameras, noise can make two rays nearly parallel and the "point" lands
+        # 1.3 - 15 km away with a pixel error under the threshold (units 387186, 1417924, 1484274 of the two-camera test,
+        # measured |dQ| 1.6e-7 - 7.9e-7 m = 1e-11 - 6e-10 relative, on both kernel paths alike,
+        # tests/sweeps/c2_far_units.py); at that depth the reference's own SVD is no better determined.  The count of
+        # units that needed the relative bar is printed, so that a growing count is visible.
+        dist = np.linalg.norm(Qr[ok], axis=1)
+        dabs = np.abs(Q[ok] - Qr[ok]).max(axis=1)
+        near = dist <= FAR_M
+        n_far = int((~near).sum())
+        if n_far:
+            print(f'{what}: {n_far} unit(s) beyond {FAR_M:.0f} m judged by the relative bar '
+                  f'(max |dQ|/|Q| = {(dabs[~near] / dist[~near]).max():.2e})')
+            assert (dabs[~near] <= TOL_Q_REL * dist[~near]).all(), \
+                f'{what}: max |dQ|/|Q| = {(dabs[~near] / dist[~near]).max():.3e} beyond {FAR_M:.0f} m'
+        dq = float(dabs[near].max()) if near.any() else 0.0
+        assert dq <= TOL_Q, f'{what}: max |dQ| = {dq:.3e} m (absolute, units within {FAR_M:.0f} m)'
         de = np.abs(err[ok].astype(np.float64) - er[ok]) / np.maximum(1.0, np.abs(er[ok]))
         assert de.max() <= TOL_E, f'{what}: error differs by {de.max():.3e}'
         return dq
