@@ -404,7 +404,9 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pool-singles', type=int, default=-1, help='kernel experiments: P2S_TUNE_POOL_SINGLES_PCT')
-    ap.add_argument('--tri-path', default='auto', choices=['auto', 'worklist', 'onetile'], help='kernel experiments (p2s_set_tuning)')
+    ap.add_argument('--tri-path', default='auto', choices=['auto', 'worklist', 'onetile', 'twotiles', 'pooled'], help='kernel experiments (p2s_set_tuning)')
+    ap.add_argument('--no-screen', action='store_true', help='kernel experiments: pooled kernel without its fp32 screen (P2S_TUNE_SCREEN 0)')
+    ap.add_argument('--pool-tiles', type=int, default=0, help='kernel experiments: P2S_TUNE_POOL_TILES')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
     args = ap.parse_args()
 
@@ -491,7 +493,12 @@ def main():
     if args.pool_singles >= 0:
         eng.set_tuning(Engine.TUNE_POOL_SINGLES_PCT, args.pool_singles)
     if args.tri_path != 'auto':
-        eng.set_tuning(Engine.TUNE_TRI_PATH, {'worklist': Engine.TRI_PATH_WORKLIST, 'onetile': Engine.TRI_PATH_ONE_TILE}[args.tri_path])
+        eng.set_tuning(Engine.TUNE_TRI_PATH, {'worklist': Engine.TRI_PATH_WORKLIST, 'onetile': Engine.TRI_PATH_ONE_TILE,
+                                              'twotiles': Engine.TRI_PATH_TWO_TILES, 'pooled': Engine.TRI_PATH_POOLED}[args.tri_path])
+    if args.no_screen:
+        eng.set_tuning(Engine.TUNE_SCREEN, 0)
+    if args.pool_tiles:
+        eng.set_tuning(Engine.TUNE_POOL_TILES, args.pool_tiles)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     prm = Engine.tri_params(cfg['thr'], cfg['lik'], cfg['min_cams'], cfg['undistort'], cfg['lr_swap'])
 
@@ -606,6 +613,7 @@ def main():
                        'accepted_fraction': ok_frac,
                        'search': {'units_entering_search_per_step': stats['search_units'], 'subsets_evaluated_per_step': stats['subsets_evaluated'],
                                   'evaluation_passes_per_step': stats['passes'],
+                                  'screened_subsets_per_step': stats['screened_subsets'], 'screen_passes_per_step': stats['screen_passes'],
                                   'capped_units_per_step': stats['capped_units']},
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

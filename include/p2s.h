@@ -181,13 +181,14 @@ int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, cons
                          const int32_t *bones, double *bone_len, double *bone_stats, double *accel, int64_t *missing);
 
 /* Counters of the triangulation calls of this context since creation (or the last reset), after synchronising its
- * streams; out holds 6 values: out[0] units that entered the camera-subset search (triangulation.py:408 beyond the
+ * streams; out holds 8 values: out[0] units that entered the camera-subset search (triangulation.py:408 beyond the
  * first pass), out[1] camera subsets evaluated, out[2] 64-lane evaluation passes, out[3] units whose search stopped at
  * the safety valve (a level with more than 2^26 subsets, i.e. C(32, 11) and beyond, is not entered: such a unit comes
  * back as not triangulated where the reference would have gone on for hours -- callers report the count), out[4]
  * per-camera reprojection errors computed for the candidates of the pruned passes (levels of hundreds of subsets and
  * more: hopeless candidates are dropped after a few cameras, so fewer than cameras x subsets), out[5] those candidates
- * (a part of out[1]). */
+ * (a part of out[1]), out[6] camera subsets looked at by the fp32 screen of the pooled kernel (only its survivors are
+ * evaluated in fp64 and counted in out[1]), out[7] 64-lane screen passes. */
 int p2s_get_tri_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 
 /* Counters of the multi-person association calls of this context since creation (or the last reset), after
@@ -228,11 +229,15 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 #define P2S_TUNE_ASSOC_FORM 8
 #define P2S_TUNE_POOL_SINGLES_PCT 9
 #define P2S_TUNE_DEEP_PRUNE 10
+#define P2S_TUNE_SCREEN 11
+#define P2S_TUNE_POOL_TILES 12
 #define P2S_ASSOC_FORM_AUTO 0
 #define P2S_ASSOC_FORM_GENERAL 1
 #define P2S_TRI_PATH_AUTO 0
 #define P2S_TRI_PATH_WORKLIST 1
 #define P2S_TRI_PATH_ONE_TILE 2
+#define P2S_TRI_PATH_POOLED 3
+#define P2S_TRI_PATH_TWO_TILES 4
 int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value);
 
 /* Kernel timing on the context's stream with HIP events: begin, enqueue work, end (blocks). */

@@ -87,6 +87,8 @@ struct p2s_ctx {
     int assoc_form = P2S_ASSOC_FORM_AUTO;
     int deep_prune = 1;                              // p2s_tri_deep.hip: exact pruning of the deep levels' evaluations
     int pool_singles_pct = 8;                        // p2s_tri_fused.hip: share of the tiles that the last workgroups take one at a time
+    int screen = 1;                                  // p2s_tri_pool.hip: fp32 screen of the camera-subset candidates
+    int pool_tiles = 3;                              // p2s_tri_pool.hip: tiles a wave streams before it searches their pooled failures (2..4)
 };
 
 namespace {
@@ -278,6 +280,7 @@ int p2s_set_calibration(p2s_ctx *ctx, int32_t n_cams, const double *P, const dou
     for (int c = 0; c < n_cams; ++c) {
         P2sCam &cam = cams[c];
         std::memcpy(cam.P, P + 12 * c, sizeof cam.P);
+        for (int i = 0; i < 12; ++i) cam.Pf[i] = (float)cam.P[i];
         if (!full) continue;
         const double *K = Kmat + 9 * c;
         cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
@@ -363,7 +366,8 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
     switch (key) {
     case P2S_TUNE_TRI_PATH:
-        if (value != P2S_TRI_PATH_AUTO && value != P2S_TRI_PATH_WORKLIST && value != P2S_TRI_PATH_ONE_TILE)
+        if (value != P2S_TRI_PATH_AUTO && value != P2S_TRI_PATH_WORKLIST && value != P2S_TRI_PATH_ONE_TILE &&
+            value != P2S_TRI_PATH_POOLED && value != P2S_TRI_PATH_TWO_TILES)
             return fail(P2S_ERR_INVALID_ARG, "unknown triangulation path %d", value);
         ctx->tri_path = value;
         return P2S_OK;
@@ -385,6 +389,11 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
     case P2S_TUNE_POOL_SINGLES_PCT:
         if (value < 0 || value > 100) return fail(P2S_ERR_INVALID_ARG, "percentage outside [0, 100]");
         ctx->pool_singles_pct = value;
+        return P2S_OK;
+    case P2S_TUNE_SCREEN: ctx->screen = value ? 1 : 0; return P2S_OK;
+    case P2S_TUNE_POOL_TILES:
+        if (value < 2 || value > 4) return fail(P2S_ERR_INVALID_ARG, "tiles per wave outside [2, 4]");
+        ctx->pool_tiles = value;
         return P2S_OK;
     case P2S_TUNE_ASSOC_FORM:
         if (value != P2S_ASSOC_FORM_AUTO && value != P2S_ASSOC_FORM_GENERAL)
@@ -438,6 +447,10 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         a.min_cams = params->min_cameras;
         a.thr = params->reproj_error_threshold;
         a.lik_thr = params->likelihood_threshold;
+        // the pooled kernel (persistent waves, fp32 screen) where it applies; P2S_TUNE_TRI_PATH picks the older forms
+        const bool pooled = (ctx->tri_path == P2S_TRI_PATH_AUTO || ctx->tri_path == P2S_TRI_PATH_POOLED) &&
+                            p2s_tri_pool_supports(C, dtype, params->undistort_points, params->handle_lr_swap);
+        a.screen = ctx->screen;
         const int64_t blk_bytes = (int64_t)C * n_kpts * 3 * elem;
         if (blk_bytes > ((int64_t)1 << 26)) return fail(P2S_ERR_INVALID_ARG, "K=%d too large", n_kpts);
         const int64_t chunk_blocks = std::max<int64_t>(16, (((int64_t)1 << 31) / blk_bytes) / 16 * 16);
@@ -445,7 +458,10 @@ int p2s_triangulate_device(p2s_ctx *ctx, int64_t n_blocks, int32_t n_kpts, int32
         for (int64_t b0 = 0; b0 < n_blocks; b0 += chunk_blocks) {
             a.block0 = b0;
             a.n_blocks = std::min<int64_t>(chunk_blocks, n_blocks - b0);
-            HIP_TRY(p2s_launch_tri_fused(a, dtype, ctx->tri_path == P2S_TRI_PATH_ONE_TILE ? 100 : ctx->pool_singles_pct, ctx->stream));
+            if (pooled)
+                HIP_TRY(p2s_launch_tri_pool(a, dtype, ctx->pool_singles_pct, ctx->pool_tiles, ctx->stream));
+            else
+                HIP_TRY(p2s_launch_tri_fused(a, dtype, ctx->tri_path == P2S_TRI_PATH_ONE_TILE ? 100 : ctx->pool_singles_pct, ctx->stream));
         }
         return P2S_OK;
     }

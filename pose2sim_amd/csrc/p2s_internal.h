@@ -16,6 +16,8 @@ struct P2sCam {
     double nk[9];          // optim_K
     double iK[9];          // inverse of the original K        (association rays)
     double center[3];      // -R^T T                            (association rays)
+    float Pf[12];          // P rounded to float: the fp32 screen of the camera-subset search (p2s_tri_pool.hip)
+    float pad_[4];
 };
 
 // Kernel diagnostics (phase stamps, memory-skeleton modes) exist only in a -DP2S_DIAG build (exp/README.md): in the
@@ -29,8 +31,9 @@ struct P2sCam {
 // p2s_get_tri_stats: [0] units that entered the camera-subset search, [1] camera subsets evaluated (lane-evaluations of
 // DLT + reprojection error beyond level 0), [2] evaluation passes (64-lane), [3] units whose search was cut short by
 // P2S_MAX_SUBSETS_PER_LEVEL (they come back as not triangulated; the reference would have gone on), [4] per-camera errors
-// computed for the candidates of the pruned passes, [5] those candidates (a part of [1])
-#define P2S_N_STATS 6
+// computed for the candidates of the pruned passes, [5] those candidates (a part of [1]), [6] camera subsets looked at by
+// the fp32 screen of p2s_tri_pool.hip (only its survivors are evaluated and counted in [1]), [7] screen passes (64-lane)
+#define P2S_N_STATS 8
 // the counters are kept in shards of their own 64-byte lines (a wave adds to shard blockIdx % P2S_STAT_SHARDS): one
 // word takes ~88 atomics per microsecond, and 40 000 waves adding to ONE word cost 1.2 ms per launch
 #define P2S_STAT_SHARDS 256
@@ -68,6 +71,7 @@ struct P2sTriArgs {
     uint32_t deep_capacity, deep_entry_bytes, deep_min_subsets;
     uint32_t max_subsets;        // search kernel: a level with more subsets is not entered (P2S_MAX_SUBSETS_PER_LEVEL unless tuned)
     uint32_t pool_pairs, pool_singles;   // p2s_tri_fused.hip: per XCD, workgroups that take two tiles, then workgroups that take one
+    int32_t screen;              // p2s_tri_pool.hip: 1 = fp32 screen of the candidates, 0 = every candidate goes to the fp64 evaluation
     int32_t prune;               // exact pruning of the subset evaluations where a wave works on one unit (search kernel, deep rounds)
     int32_t job;                 // work-list records a search wave takes at a time (<= 64); sizes its LDS region
     int32_t debug_mode;          // 0 = normal; diagnostics only: 1 = stage + store (no compute), 2 = every tile reads tile 0
@@ -133,6 +137,9 @@ hipError_t p2s_launch_tri(const P2sTriArgs &a, int dtype, const P2sTriLaunch &g,
 // cameras two tiles per wave, except for the last singles_pct % of every XCD's tiles
 bool p2s_tri_fused_supports(int C, int dtype, int undistort, int lr_swap);
 hipError_t p2s_launch_tri_fused(const P2sTriArgs &a, int dtype, int singles_pct, hipStream_t s);
+// p2s_tri_pool.hip: persistent waves, failures pooled across tiles, fp32 screen + fp64 evaluation of the survivors
+bool p2s_tri_pool_supports(int C, int dtype, int undistort, int lr_swap);
+hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int dtype, int singles_pct, int tiles_per_wave, hipStream_t s);
 struct P2sSingleArgs {
     const int32_t *n_persons;   // [F][C]
     const int64_t *offsets;     // [F+1]

@@ -1,0 +1,627 @@
+// p2s_tri_pool.hip -- one-launch robust triangulation for gfx950 (MI355X, CDNA4), round 3: persistent waves that stream
+// tile after tile, POOL the units whose level-0 error exceeds the threshold in LDS slots across tiles, and search their
+// camera subsets (triangulation_from_best_cameras, triangulation.py:363-604) in two tiers:
+//
+//   tier A (screen, fp32): every candidate subset of a level is evaluated in single precision in coordinates centred on
+//     the unit's level-0 point -- normal matrix of the kept cameras by downdate, smallest eigenpair by two Rayleigh
+//     steps, mean reprojection error -- at about half the issue cost of the fp64 evaluation (exp/valu_rates.hip: a
+//     wave64 v_fma_f32 holds the SIMD ~2.9 cycles, a v_fma_f64 ~5.4).  It decides nothing by itself: a candidate is dropped
+//     only if its fp32 error, minus a margin that is 30x the largest deviation from the fp64 error seen on any workload
+//     (exp/screen_proto.py, tests/sweeps), cannot be the level's minimum and -- on a level that is not the unit's last,
+//     so that a failed level leaves nothing behind -- cannot be under the threshold.  Candidates the screen cannot vouch
+//     for (ill-conditioned system, eigen-iteration not settled, irregular projection, level-0 point far away or not
+//     finite) always go on.
+//   tier B (fp64): the survivors -- 0.93 per searching unit on BASELINE configs[1] instead of 8 -- of ALL the pooled
+//     units and levels are evaluated together, one per lane, by exactly the arithmetic of level 0; the argmin per unit
+//     (error, then rank: np.nanargmin's first index) goes through LDS atomics.
+//
+// A unit whose level certainly failed in tier A goes on to the next level's screen at once, so that one fp64 pass
+// serves the survivors of several levels.  Every number that reaches a result comes from tier B: with the screen switched
+// off (P2S_TUNE_SCREEN 0: every candidate survives) the outputs are bit-identical (tests/test_tri_gpu.py).
+//
+// Why persistent: a wave that streams two tiles has 15 searching units; their level-1 candidates fill 2 screen passes
+// but their survivors only a quarter of one fp64 pass.  Here the slots fill up over ~3 tiles before a search runs, the
+// results of a tile leave at once (16-byte stores) and the searched units' results are patched afterwards.
+//
+// Scope: pinhole path without L/R swap (both off in every shipped configuration), up to 16 cameras
+// (8 for float64 input); everything else takes the kernels of p2s_tri.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "p2s_internal.h"
+#include "p2s_tri_dev.h"
+
+namespace {
+
+#ifndef P2S_POOL_WPS
+#define P2S_POOL_WPS 3          // waves per SIMD the register allocation aims at
+#endif
+constexpr uint32_t kNone = 0xffffffffu;
+constexpr float kInfF = __builtin_huge_valf();
+
+template <typename T, int CT>
+struct alignas(16) QSlot {
+    double N[10];                          // normal matrix of all valid cameras
+    double q[3];                           // level-0 point until the base below is built, then the verified best's point
+    unsigned long long ebits;              // verified best error of the current level (bits of a non-negative double), ~0 = none
+    T o[CT * 3];                           // x, y, likelihood per camera
+    float M[6], g[3], h, c0[3];            // screen base: normal matrix of all valid cameras about c0 (the level-0 point)
+    uint32_t rank, S;                      // verified best: rank in itertools order (atomic min among equal errors), subset
+    uint32_t nan, zero;
+    uint32_t unit;                         // unit index within the chunk
+    uint32_t surv;                         // the current level's screen let somebody through
+};
+
+template <typename T>
+struct SlotObs {
+    const T *o;
+    double lik_thr;
+    __device__ __forceinline__ void raw(int c, double &x, double &y, double &wo) const {
+        x = (double)o[3 * c]; y = (double)o[3 * c + 1]; wo = 0.0;
+    }
+    __device__ __forceinline__ void rawT(int c, T &x, T &y, T &wo) const { x = o[3 * c]; y = o[3 * c + 1]; wo = o[3 * c + 2]; }
+};
+
+template <typename T, int CT, bool EXACT>
+__device__ __forceinline__ void load_obs(const P2sTriArgs &a, int C, uint32_t b, uint32_t k, RegObs<T, CT> &obs) {
+    const unsigned char *chunk = reinterpret_cast<const unsigned char *>(a.xyl) +
+                                 (size_t)a.block0 * (size_t)C * (size_t)a.K * 3u * sizeof(T);
+    const uint32_t voff = (b * (uint32_t)(C * a.K) + k) * (uint32_t)(3 * sizeof(T));   // < 2^32: chunked on the host
+    const uint32_t cam_stride = (uint32_t)a.K * (uint32_t)(3 * sizeof(T));
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        if (EXACT || c < C) {
+            const T *p = reinterpret_cast<const T *>(chunk + (size_t)c * cam_stride + voff);
+            obs.x[c] = __builtin_nontemporal_load(p);
+            obs.y[c] = __builtin_nontemporal_load(p + 1);
+            obs.w[c] = __builtin_nontemporal_load(p + 2);
+        } else {
+            obs.x[c] = obs.y[c] = obs.w[c] = (T)0;
+        }
+    }
+}
+
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- tier A arithmetic (fp32) ---------------------------------------------------------------------------------------
+// q = (M - lam I)^-1 r through the adjugate; det and trace of M - lam I for the conditioning guard.
+struct Sym3f { float m00, m01, m02, m11, m12, m22; };
+
+__device__ __forceinline__ void solve3f(const Sym3f &M, float lam, float r0, float r1, float r2, float &q0, float &q1, float &q2,
+                                        float &det, float &tr, bool &pd) {
+    const float a00 = M.m00 - lam, a11 = M.m11 - lam, a22 = M.m22 - lam;
+    const float c00 = fmaf(a11, a22, -M.m12 * M.m12);
+    const float c01 = fmaf(M.m02, M.m12, -M.m01 * a22);
+    const float c02 = fmaf(M.m01, M.m12, -M.m02 * a11);
+    const float c11 = fmaf(a00, a22, -M.m02 * M.m02);
+    const float c12 = fmaf(M.m01, M.m02, -a00 * M.m12);
+    const float c22 = fmaf(a00, a11, -M.m01 * M.m01);
+    det = fmaf(a00, c00, fmaf(M.m01, c01, M.m02 * c02));
+    const float id = __builtin_amdgcn_rcpf(det);
+    q0 = fmaf(c00, r0, fmaf(c01, r1, c02 * r2)) * id;
+    q1 = fmaf(c01, r0, fmaf(c11, r1, c12 * r2)) * id;
+    q2 = fmaf(c02, r0, fmaf(c12, r1, c22 * r2)) * id;
+    tr = a00 + a11 + a22;
+    pd = (a00 > 0.0f) && (c22 > 0.0f) && (det > 0.0f);
+}
+
+// Rayleigh quotient of v = (q, 1) for the pencil (N', G) of the shifted problem: N' = [[M, g], [g^T, h]],
+// G = T^T T with T the translation by c0, i.e. v^T G v = |c0 + q|^2 + 1.
+__device__ __forceinline__ float rayleighf(const Sym3f &M, float g0, float g1, float g2, float h, float c0, float c1, float c2,
+                                           float q0, float q1, float q2) {
+    const float t0 = fmaf(M.m00, q0, fmaf(M.m01, q1, M.m02 * q2));
+    const float t1 = fmaf(M.m01, q0, fmaf(M.m11, q1, M.m12 * q2));
+    const float t2 = fmaf(M.m02, q0, fmaf(M.m12, q1, M.m22 * q2));
+    const float num = fmaf(q0, fmaf(2.0f, g0, t0), fmaf(q1, fmaf(2.0f, g1, t1), fmaf(q2, fmaf(2.0f, g2, t2), h)));
+    const float Q0 = c0 + q0, Q1 = c1 + q1, Q2 = c2 + q2;
+    const float den = fmaf(Q0, Q0, fmaf(Q1, Q1, fmaf(Q2, Q2, 1.0f)));
+    return num * __builtin_amdgcn_rcpf(den);
+}
+
+// The screen's margin and guards (exp/screen_proto.py): with det / tr^3 >= 3e-3 (condition number of M - lam I below
+// ~330), the last two eigenvalue estimates within 25 % of each other, a finite result and the level-0 point within 30 m,
+// |e32 - e64| stayed under 0.03 (0.02 px + e (1e-3 + 2 dlam)) on every candidate of every workload tried.
+constexpr float kCondMin = 3e-3f, kDlamMax = 0.25f, kMargAbs = 0.02f, kMargRel = 1e-3f, kMargDlam = 2.0f, kCentreMax2 = 900.0f;
+
+template <typename T, int CT, int NSLOT, bool EXACT, int TPW>
+__global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2sTriArgs a) {
+    typedef QSlot<T, CT> slot_t;
+    __shared__ __align__(16) unsigned char smem[sizeof(slot_t) * NSLOT];
+    __shared__ __align__(16) double sP[CT * 12];
+    __shared__ __align__(16) float sPf[CT * 12];
+    __shared__ uint8_t sOver[64 * TPW];                  // units that found no slot: (tile within the wave) * 64 + lane, in order
+    // One region, two lives: the results of the tile being streamed, staged for its 16-byte stores -- and, while a search
+    // runs (the tile's results have left by then), the list of pending slots and the survivors awaiting tier B.
+    __shared__ __align__(16) unsigned char sShare[64 * 24 + 64 * 4 + 64 * 4 + 64];
+    slot_t *slots = reinterpret_cast<slot_t *>(smem);
+    double *sQ = reinterpret_cast<double *>(sShare);
+    uint32_t *sE = reinterpret_cast<uint32_t *>(sShare + 1536);
+    uint32_t *sM = reinterpret_cast<uint32_t *>(sShare + 1792);
+    uint8_t *sX = sShare + 2048;
+    uint2 *sSurv = reinterpret_cast<uint2 *>(sShare);    // 128 entries: {slot | subset << 8, rank}
+    uint32_t *sList = reinterpret_cast<uint32_t *>(sShare + 1024);
+
+    const int C = EXACT ? CT : a.C;
+    const int K = a.K;
+    cam_cptr cams = (cam_cptr)a.cams;
+    const int lane = threadIdx.x;
+    const int64_t n_units = a.n_blocks * K;
+    const uint32_t n_tiles = (uint32_t)((n_units + 63) >> 6);
+    // Workgroups are dealt round-robin over the 8 XCDs: every XCD gets a contiguous range of tiles, so that the partial
+    // (frame, camera) runs two neighbouring tiles share are fetched into one L2 only; within it the first workgroups take
+    // TPW tiles each (tiles xj, xj + n, xj + 2n of the range, n = such workgroups per XCD: neighbouring tiles are streamed
+    // by neighbouring workgroups at about the same time) and the last ones a single tile: the waves that start last are
+    // the short ones, so the grid drains quickly.
+    const uint32_t per_xcd = (n_tiles + 7u) >> 3;
+    const uint32_t xj = blockIdx.x >> 3;
+    if (xj >= a.pool_pairs + a.pool_singles) return;
+    const bool multi = xj < a.pool_pairs;
+    const uint32_t tstride = multi ? a.pool_pairs : 0u;
+    const uint32_t tile0 = (blockIdx.x & 7u) * per_xcd + (multi ? xj : TPW * a.pool_pairs + (xj - a.pool_pairs));
+    const int my_tiles = multi ? TPW : 1;
+    if (tile0 >= n_tiles) return;
+    const double thr = a.thr;
+    const float thr_f = (float)(thr * (1.0 + 1e-6));
+    const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const bool screen_on = a.screen != 0;
+    for (int i = lane; i < C * 12; i += 64) { sP[i] = a.cams[i / 12].P[i % 12]; sPf[i] = (float)a.cams[i / 12].P[i % 12]; }
+
+    int n_used = 0, n_over = 0;                          // slots in use, units waiting in sOver (wave-uniform)
+    uint32_t st_units = 0, st_evals = 0, st_passes = 0, st_screened = 0, st_spasses = 0;
+
+    auto unit_of = [&](uint32_t t, bool &active) -> uint32_t {
+        const int64_t lu = ((int64_t)t << 6) + lane;
+        active = lu < n_units;
+        return active ? (uint32_t)lu : (uint32_t)(t << 6);
+    };
+    auto fill_slot = [&](slot_t &s, const double N[10], const double q[3], uint32_t nanmask, uint32_t zeromask, uint32_t unit,
+                         const RegObs<T, CT> &obs) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s.N[i] = N[i];
+        s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
+        s.nan = nanmask; s.zero = zeromask; s.unit = unit;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { s.o[3 * c] = obs.x[c]; s.o[3 * c + 1] = obs.y[c]; s.o[3 * c + 2] = obs.w[c]; }
+    };
+
+    // ---- the search over the pooled slots (and then over the units that found no slot) ---------------------------------
+    auto flush = [&]() {
+        int cnt = n_used;
+        int over_done = 0;
+        for (;;) {
+            wsync();
+            const bool own = lane < cnt;                                    // lane s looks after slot s
+            slot_t &mine = slots[own ? lane : 0];
+            const uint32_t m_nan = mine.nan, m_d = mine.nan | mine.zero, m_valid = allmask & ~m_d;
+            const int m_V = __popc(m_d), m_Lmax = C - a.min_cams - m_V;
+            if (own) {
+                // screen base: N' = T^T N T about c0 = the level-0 point (fp64, then rounded: g and h are what is left
+                // of M c0 + b and c0.(M c0 + 2b) + c after cancellation)
+                const double c0 = mine.q[0], c1 = mine.q[1], c2 = mine.q[2];
+                const double *N = mine.N;
+                const double g0 = fma(N[0], c0, fma(N[1], c1, fma(N[2], c2, N[3])));
+                const double g1 = fma(N[1], c0, fma(N[4], c1, fma(N[5], c2, N[6])));
+                const double g2 = fma(N[2], c0, fma(N[5], c1, fma(N[7], c2, N[8])));
+                const double hh = fma(c0, g0 + N[3], fma(c1, g1 + N[6], fma(c2, g2 + N[8], N[9])));
+                mine.M[0] = (float)N[0]; mine.M[1] = (float)N[1]; mine.M[2] = (float)N[2];
+                mine.M[3] = (float)N[4]; mine.M[4] = (float)N[5]; mine.M[5] = (float)N[7];
+                mine.g[0] = (float)g0; mine.g[1] = (float)g1; mine.g[2] = (float)g2; mine.h = (float)hh;
+                const bool centred = (c0 * c0 + c1 * c1 + c2 * c2) < (double)kCentreMax2;   // false for NaN
+                mine.c0[0] = centred ? (float)c0 : __builtin_nanf(""); mine.c0[1] = (float)c1; mine.c0[2] = (float)c2;
+                mine.ebits = ~0ull; mine.rank = kNone; mine.S = 0u; mine.surv = 0u;
+            }
+            enum { ST_DONE = 0, ST_NEED_A = 1, ST_WAIT_B = 2 };
+            int state = own ? ST_NEED_A : ST_DONE, mylevel = 1;
+            st_units += (uint32_t)cnt;
+            wsync();
+
+            // Wave-uniform scheduler: screen rounds level by level; an fp64 pass whenever 64 survivors wait, and to drain
+            // the list once no unit can be screened further; then the owners read their level's verdict.
+            enum { PH_NEXT_LEVEL, PH_ROUND, PH_DRAIN };
+            int phase = PH_NEXT_LEVEL, level = 0, npend = 0, lg = 2, p0 = 0;
+            uint32_t r0 = 0, sub0 = 0, nsub = 0, nSurv = 0;
+            unsigned long long levmask = 0ull;
+            float run_hi = kInfF;
+            for (;;) {
+                while (nSurv >= 64u || (phase == PH_DRAIN && nSurv > 0u)) {
+                    // ---- tier B: fp64 evaluation of up to 64 survivors, one per lane --------------------------------------
+                    wsync();
+                    const uint32_t n = min(64u, nSurv);
+                    const bool go = (uint32_t)lane < n;
+                    const uint2 ent = sSurv[go ? lane : 0];
+                    slot_t &s = slots[ent.x & 0xffu];
+                    const uint32_t S = ent.x >> 8, r = ent.y;
+                    const uint32_t o_d = s.nan | s.zero, o_valid = allmask & ~o_d;
+                    const uint32_t Rreal = S & o_valid, kept = o_valid & ~Rreal;
+                    const int nkept = __popc(kept);
+                    SlotObs<T> sobs{s.o, a.lik_thr};
+                    double Ns[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) Ns[i] = s.N[i];
+                    for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                        const bool on = rr != 0u;
+                        const int c = on ? __builtin_ctz(rr) : 0;
+                        const T x = s.o[3 * c], y = s.o[3 * c + 1], w = s.o[3 * c + 2];
+                        accum_camera<-1>(Ns, sP + c * 12, (double)(on ? x : (T)0), (double)(on ? y : (T)0), (double)(on ? w : (T)0));
+                    }
+                    double q[3];
+                    smallest_eigvec(Ns, q);
+                    if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
+                    // the projection matrices are scalar loads at their point of use: an opaque copy of the pointer keeps the
+                    // compiler from hoisting 192 SGPRs' worth of them out of the loops
+                    cam_cptr cams_here = cams;
+                    asm volatile("" : "+s"(cams_here));
+                    const double e = mean_error<T, false, CT>(cams_here, C, sobs, kept, q);
+                    // argmin per unit on (error, rank), np.nanargmin (triangulation.py:500-503): the bits of a non-negative
+                    // double order like the value, inf above every number and NaN above inf, so a NaN only wins among NaNs
+                    const unsigned long long bits = (e == e) ? (unsigned long long)__double_as_longlong(e) : 0x7ff8000000000000ull;
+                    // (a unit's survivors may come in several passes: a pass that lowers the error starts the rank afresh)
+                    const unsigned long long before = s.ebits;
+                    wsync();
+                    if (go) atomicMin(&s.ebits, bits);
+                    wsync();
+                    const bool first = go && (s.ebits == bits);
+                    if (first && bits < before) s.rank = kNone;
+                    wsync();
+                    if (first) atomicMin(&s.rank, r);
+                    wsync();
+                    if (first && s.rank == r) { s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2]; s.S = S; }
+                    st_evals += n; ++st_passes;
+                    // what is left of the list moves to its head (at most 63 entries)
+                    const uint32_t rem = nSurv - n;
+                    const uint2 mv = sSurv[((uint32_t)lane < rem) ? 64 + lane : 0];
+                    wsync();
+                    if ((uint32_t)lane < rem) sSurv[lane] = mv;
+                    nSurv = rem;
+                    wsync();
+                }
+                if (phase == PH_DRAIN) {
+                    wsync();
+                    if (state == ST_WAIT_B) {
+                        const double e = __longlong_as_double((long long)mine.ebits);
+                        if (!(e <= thr) && (e > thr) && (mylevel + 1 <= m_Lmax)) {          // :408: on to the next level
+                            ++mylevel; state = ST_NEED_A;
+                            mine.ebits = ~0ull; mine.rank = kNone; mine.surv = 0u;
+                        } else {
+                            state = ST_DONE;
+                        }
+                    }
+                    if (!__any(state == ST_NEED_A)) break;
+                    wsync();
+                    phase = PH_NEXT_LEVEL; level = 0;
+                    continue;
+                }
+                if (phase == PH_NEXT_LEVEL) {
+                    if (!__any(state == ST_NEED_A)) { phase = PH_DRAIN; continue; }
+                    ++level;
+                    const bool at = (state == ST_NEED_A) && (mylevel == level);
+                    const unsigned long long pend = __ballot(at);
+                    if (pend == 0ull) continue;
+                    wsync();
+                    npend = __popcll(pend);
+                    if (at) sList[__popcll(pend & lt)] = (uint32_t)lane;
+                    wsync();
+                    sub0 = a.sub_off[level];
+                    nsub = a.sub_off[level + 1] - sub0;
+                    {
+                        uint32_t best_cost = 0xffffffffu;
+                        for (int l = 2; l <= 6; ++l) {
+                            const uint32_t passes = (((uint32_t)npend << l) + 63u) >> 6;
+                            const uint32_t rounds = (nsub + (1u << l) - 1u) >> l;
+                            const uint32_t cost = passes * rounds;
+                            if (cost <= best_cost) { best_cost = cost; lg = l; }
+                        }
+                    }
+                    p0 = 0; r0 = 0; run_hi = kInfF; levmask = pend;
+                    phase = PH_ROUND;
+                    continue;
+                }
+                // ---- tier A: one round of the screen; lane j of a group looks at subset #(r0 + j) of its unit's level ----
+                {
+                    const int G = 1 << lg, groups = 64 >> lg;
+                    const int grp = lane >> lg, lig = lane & (G - 1);
+                    const bool has = p0 + grp < npend;
+                    const uint32_t si = sList[has ? p0 + grp : p0];
+                    slot_t &s = slots[si];
+                    const uint32_t o_d = s.nan | s.zero, o_valid = allmask & ~o_d;
+                    const bool last = level >= C - a.min_cams - __popc(o_d);         // the unit's last level: its minimum counts whatever it is
+                    const uint32_t r = r0 + (uint32_t)lig;
+                    bool go = has && (r < nsub);
+                    uint32_t S = 0;
+                    if (go) {
+                        // level 1 is rank r <-> camera r (itertools.combinations order); the deeper levels go to the table
+                        S = (level == 1) ? (1u << r) : (uint32_t)a.sub_tab[sub0 + r];
+                        // quirk Q1 duplicates: only the lexicographically first padding can win the argmin
+                        const uint32_t pad = S & o_d;
+                        const uint32_t below = pad ? ((2u << (31 - __builtin_clz(pad))) - 1u) : 0u;
+                        go = (o_d & below) == pad;
+                    }
+                    if (__any(go)) {
+                        const uint32_t Rreal = S & o_valid, kept = o_valid & ~Rreal;
+                        const int nkept = __popc(kept);
+                        float e_lo = -kInfF, e_hi = kInfF;
+                        if (screen_on) {
+                            Sym3f M{s.M[0], s.M[1], s.M[2], s.M[3], s.M[4], s.M[5]};
+                            float g0 = s.g[0], g1 = s.g[1], g2 = s.g[2], h = s.h;
+                            const float c0 = s.c0[0], c1 = s.c0[1], c2 = s.c0[2];
+                            for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                                const bool on = rr != 0u;
+                                const int c = on ? __builtin_ctz(rr) : 0;
+                                const float x = on ? (float)s.o[3 * c] : 0.0f, y = on ? (float)s.o[3 * c + 1] : 0.0f;
+                                const float w = on ? (float)s.o[3 * c + 2] : 0.0f;
+                                const float *P = sPf + c * 12;
+                                const float A0 = fmaf(-x, P[8], P[0]), A1 = fmaf(-x, P[9], P[1]), A2 = fmaf(-x, P[10], P[2]), A3 = fmaf(-x, P[11], P[3]);
+                                const float B0 = fmaf(-y, P[8], P[4]), B1 = fmaf(-y, P[9], P[5]), B2 = fmaf(-y, P[10], P[6]), B3 = fmaf(-y, P[11], P[7]);
+                                const float u = fmaf(A0, c0, fmaf(A1, c1, fmaf(A2, c2, A3)));
+                                const float v = fmaf(B0, c0, fmaf(B1, c1, fmaf(B2, c2, B3)));
+                                const float w2 = w * w;
+                                const float a0 = A0 * w2, a1 = A1 * w2, a2 = A2 * w2, b0 = B0 * w2, b1 = B1 * w2, b2 = B2 * w2;
+                                M.m00 = fmaf(-a0, A0, fmaf(-b0, B0, M.m00)); M.m01 = fmaf(-a0, A1, fmaf(-b0, B1, M.m01));
+                                M.m02 = fmaf(-a0, A2, fmaf(-b0, B2, M.m02)); M.m11 = fmaf(-a1, A1, fmaf(-b1, B1, M.m11));
+                                M.m12 = fmaf(-a1, A2, fmaf(-b1, B2, M.m12)); M.m22 = fmaf(-a2, A2, fmaf(-b2, B2, M.m22));
+                                g0 = fmaf(-a0, u, fmaf(-b0, v, g0)); g1 = fmaf(-a1, u, fmaf(-b1, v, g1)); g2 = fmaf(-a2, u, fmaf(-b2, v, g2));
+                                h = fmaf(-w2 * u, u, fmaf(-w2 * v, v, h));
+                            }
+                            // smallest eigenpair of the pencil: (M - lam) q = lam c0 - g, lam = Rayleigh quotient; from
+                            // lam = 0 (the inhomogeneous least-squares point) two steps leave |dlam / lam| ~ 1e-4 or less
+                            float q0, q1, q2, det, tr;
+                            bool pd;
+                            solve3f(M, 0.0f, -g0, -g1, -g2, q0, q1, q2, det, tr, pd);
+                            const float lam1 = rayleighf(M, g0, g1, g2, h, c0, c1, c2, q0, q1, q2);
+                            solve3f(M, lam1, fmaf(lam1, c0, -g0), fmaf(lam1, c1, -g1), fmaf(lam1, c2, -g2), q0, q1, q2, det, tr, pd);
+                            const float lam2 = rayleighf(M, g0, g1, g2, h, c0, c1, c2, q0, q1, q2);
+                            solve3f(M, lam2, fmaf(lam2, c0, -g0), fmaf(lam2, c1, -g1), fmaf(lam2, c2, -g2), q0, q1, q2, det, tr, pd);
+                            const float dlam = fabsf(lam2 - lam1) * __builtin_amdgcn_rcpf(fabsf(lam2));
+                            const float Q0 = c0 + q0, Q1 = c1 + q1, Q2 = c2 + q2;
+                            // mean reprojection error of the kept cameras, |(a/z - x, b/z - y)| = s / sqrt(s z^2)
+                            float sum = 0.0f;
+                            bool regular = true;
+                            cam_cptr cams_here = cams;
+                            asm volatile("" : "+s"(cams_here));
+                            for_each_cam<CT>(C, [&](int c) {
+                                const __attribute__((address_space(4))) float *P = cams_here[c].Pf;
+                                const float x = (float)s.o[3 * c], y = (float)s.o[3 * c + 1];
+                                const float pa = fmaf(P[0], Q0, fmaf(P[1], Q1, P[2] * Q2)) + P[3];
+                                const float pb = fmaf(P[4], Q0, fmaf(P[5], Q1, P[6] * Q2)) + P[7];
+                                const float pz = fmaf(P[8], Q0, fmaf(P[9], Q1, P[10] * Q2)) + P[11];
+                                const float du = fmaf(-x, pz, pa), dv = fmaf(-y, pz, pb);
+                                const float ss = fmaf(du, du, dv * dv);
+                                const float t = ss * pz * pz;
+                                const bool k = (kept >> c) & 1u;
+                                regular = regular && (!k || ((t > 0.0f) && (t < kInfF) && (pz > 0.0f)));
+                                const float d = ss * __builtin_amdgcn_rsqf(t);
+                                sum += k ? d : 0.0f;
+                            });
+                            const float e32 = sum * __builtin_amdgcn_rcpf((float)nkept);
+                            const bool guarded = pd && regular && (nkept >= 2) && (det >= kCondMin * tr * tr * tr) && (dlam <= kDlamMax) &&
+                                                 (e32 < kInfF);                       // false for NaN anywhere above
+                            const float marg = fmaf(e32, fmaf(kMargDlam, dlam, kMargRel), kMargAbs);
+                            e_lo = guarded ? e32 - marg : -kInfF;
+                            e_hi = guarded ? e32 + marg : kInfF;
+                        }
+                        if (!go) { e_lo = kInfF; e_hi = kInfF; }
+                        float gmin = e_hi;
+                        for (int off = G >> 1; off > 0; off >>= 1) gmin = fminf(gmin, __shfl_xor(gmin, off, 64));
+                        run_hi = fminf(run_hi, gmin);
+                        // the true minimum w of the level has e_lo(w) <= e64(w) <= e64(S) <= e_hi(S) for every S seen so far
+                        const bool surv = go && (e_lo <= run_hi) && (last || e_lo <= thr_f);
+                        const unsigned long long sb = __ballot(surv);
+                        if (sb != 0ull) {
+                            if (surv) {
+                                sSurv[nSurv + (uint32_t)__popcll(sb & lt)] = make_uint2(si | (S << 8), r);
+                                s.surv = 1u;
+                            }
+                            nSurv += (uint32_t)__popcll(sb);
+                        }
+                        st_screened += (uint32_t)__popcll(__ballot(go)); ++st_spasses;
+                    }
+                    r0 += (uint32_t)G;
+                    if (r0 >= nsub) { r0 = 0; p0 += groups; run_hi = kInfF; }
+                    if (p0 >= npend) {
+                        // the level's screen is through: a unit nobody survived for has certainly failed the level and,
+                        // unless it was its last (where somebody always survives), goes on to the next one at once
+                        wsync();
+                        if ((levmask >> lane) & 1ull) {
+                            if (mine.surv != 0u || level >= m_Lmax) state = ST_WAIT_B;
+                            else mylevel = level + 1;
+                        }
+                        phase = PH_NEXT_LEVEL;
+                    }
+                }
+            }
+
+            // ---- results of the searched units (triangulation.py:588-604), patched over what their tile stored ------------
+            if (own) {
+                const double e = __longlong_as_double((long long)mine.ebits);
+                const uint32_t bS = mine.S;
+                const bool ok = e <= thr;
+                const int64_t gu = a.block0 * K + (int64_t)mine.unit;
+                a.Q[gu * 3 + 0] = ok ? mine.q[0] : d_nan();
+                a.Q[gu * 3 + 1] = ok ? mine.q[1] : d_nan();
+                a.Q[gu * 3 + 2] = ok ? mine.q[2] : d_nan();
+                a.err[gu] = ok ? (float)e : __builtin_nanf("");
+                a.mask[gu] = m_nan | bS;
+                a.n_excl[gu] = (uint8_t)(m_V + __popc(bS & m_valid));          // :436 counts NaN or zero
+            }
+            // ---- units that found no slot: read their observations again, rebuild level 0, search them the same way -------
+            if (n_over - over_done <= 0) break;
+            cnt = min(NSLOT, n_over - over_done);
+            wsync();
+            if (lane < cnt) {
+                const uint32_t o = sOver[over_done + lane];
+                const uint32_t u = ((tile0 + (o >> 6) * tstride) << 6) + (o & 63u);
+                const uint32_t b = u / (uint32_t)K, k = u - b * (uint32_t)K;
+                RegObs<T, CT> ob;
+                ob.lik_thr = a.lik_thr;
+                load_obs<T, CT, EXACT>(a, C, b, k, ob);
+                double N2[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) N2[i] = 0.0;
+                uint32_t nan2 = 0, zero2 = 0;
+                classify_and_accumulate<T, CT>(cams, C, ob, N2, nan2, zero2);
+                double q2[3];
+                smallest_eigvec(N2, q2);
+                fill_slot(slots[lane], N2, q2, nan2, zero2, u, ob);
+            }
+            over_done += cnt;
+        }
+        n_used = 0; n_over = 0;
+    };
+
+    // ---- level 0 of the wave's tiles (triangulation.py:404-505 with nb_cams_off = 0), one after the other ---------------
+    // `prefetch` is called once the eigen-solve is through (the point of highest register pressure): a tile requests the
+    // next tile's observations there, so that they travel during its reprojection pass instead of after it.
+    auto level0 = [&](const int t, const bool act, const RegObs<T, CT> &cur, auto &&prefetch) {
+        const uint32_t tile = tile0 + (uint32_t)t * tstride;
+        double N[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) N[i] = 0.0;
+        uint32_t nanmask = 0, zeromask = 0;
+        classify_and_accumulate<T, CT>(cams, C, cur, N, nanmask, zeromask);
+        const uint32_t dmask = nanmask | zeromask;
+        const uint32_t valid = allmask & ~dmask;
+        const int V = __popc(dmask);
+        const int Lmax = act ? C - a.min_cams - V : -1;                   // last level that runs (:408, :437-441)
+        double q[3];
+        smallest_eigvec(N, q);
+        prefetch(q[0]);
+        if (C - V < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }  // common.py:347: fewer than 4 rows
+        const double e = mean_error<T, false, CT>(cams, C, cur, valid, q);
+        const bool ran = Lmax >= 0;                                        // else no level completes (:595-596)
+        const bool ok = ran && (e <= thr);                                 // :600-602
+        if (t > 0) wsync();                                                // the previous tile's staged results have left
+        sQ[lane * 3 + 0] = ok ? q[0] : d_nan();
+        sQ[lane * 3 + 1] = ok ? q[1] : d_nan();
+        sQ[lane * 3 + 2] = ok ? q[2] : d_nan();
+        sE[lane] = __float_as_uint(ok ? (float)e : __builtin_nanf(""));
+        sM[lane] = ran ? nanmask : allmask;
+        sX[lane] = (uint8_t)(ran ? V : C);
+        // goes on to level 1 (then at least 3 cameras are valid: q is the solve's own point, the centre of the screen)
+        const bool need = (Lmax >= 1) && (e > thr);
+        const unsigned long long hard = __ballot(need);
+        if (need) {
+            const int ord = n_used + n_over + __popcll(hard & lt);
+            if (ord < NSLOT) fill_slot(slots[ord], N, q, nanmask, zeromask, (tile << 6) + (uint32_t)lane, cur);
+            else sOver[ord - NSLOT] = (uint8_t)(t * 64 + lane);
+        }
+        {
+            const int tot = n_used + n_over + __popcll(hard);
+            n_over = max(0, tot - NSLOT);
+            n_used = min(NSLOT, tot);
+        }
+        // ---- the tile's results leave at once, 16-byte stores of contiguous memory; the searching units' results are
+        // patched over them after the search
+        wsync();
+        {
+            const int64_t wave_u0 = (int64_t)tile << 6;
+            const int64_t gu0 = a.block0 * K + wave_u0;
+            const int64_t n_left = n_units - wave_u0;
+            double *Qw = a.Q + gu0 * 3;
+            float *Ew = a.err + gu0;
+            uint32_t *Mw = a.mask + gu0;
+            uint8_t *Xw = a.n_excl + gu0;
+            const bool al16 = ((reinterpret_cast<uintptr_t>(Qw) | reinterpret_cast<uintptr_t>(Ew) |
+                                reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(Xw)) & 15) == 0;
+            if (n_left >= 64 && al16) {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v2d *src = reinterpret_cast<const v2d *>(sQ);
+                v2d *dst = reinterpret_cast<v2d *>(Qw);
+                dst[lane] = src[lane];
+                if (lane < 32) dst[64 + lane] = src[64 + lane];
+                else if (lane < 48) reinterpret_cast<v4u *>(Ew)[lane - 32] = reinterpret_cast<const v4u *>(sE)[lane - 32];
+                else if (lane < 52) reinterpret_cast<v4u *>(Xw)[lane - 48] = reinterpret_cast<const v4u *>(sX)[lane - 48];
+                if (lane < 16) reinterpret_cast<v4u *>(Mw)[lane] = reinterpret_cast<const v4u *>(sM)[lane];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int idx = r * 64 + lane;
+                    if (idx < 3 * n_left) Qw[idx] = sQ[idx];
+                }
+                if (lane < n_left) { Ew[lane] = __uint_as_float(sE[lane]); Mw[lane] = sM[lane]; Xw[lane] = sX[lane]; }
+            }
+        }
+    };
+    RegObs<T, CT> obs0, obs1, obs2, obs3;
+    obs0.lik_thr = a.lik_thr; obs1.lik_thr = a.lik_thr; obs2.lik_thr = a.lik_thr; obs3.lik_thr = a.lik_thr;
+    bool act0, act1 = false, act2 = false, act3 = false;
+    const uint32_t u0 = unit_of(tile0, act0);
+    load_obs<T, CT, EXACT>(a, C, u0 / (uint32_t)K, u0 % (uint32_t)K, obs0);
+    const bool two = my_tiles > 1 && tile0 + tstride < n_tiles;
+    const bool three = TPW > 2 && my_tiles > 2 && tile0 + 2 * tstride < n_tiles;
+    const bool four = TPW > 3 && my_tiles > 3 && tile0 + 3 * tstride < n_tiles;
+    auto request = [&](const bool wanted, const int t, bool &act, RegObs<T, CT> &obs, double dep) {
+        if (wanted) {
+            uint32_t u = unit_of(tile0 + (uint32_t)t * tstride, act);
+            asm volatile("" : "+v"(u) : "v"(dep));                         // not before the eigen-solve
+            load_obs<T, CT, EXACT>(a, C, u / (uint32_t)K, u % (uint32_t)K, obs);
+        }
+    };
+    level0(0, act0, obs0, [&](double dep) { if constexpr (TPW > 1) request(two, 1, act1, obs1, dep); });
+    if constexpr (TPW > 1) {
+        if (two) level0(1, act1, obs1, [&](double dep) { if constexpr (TPW > 2) request(three, 2, act2, obs2, dep); });
+    }
+    if constexpr (TPW > 2) {
+        if (three) level0(2, act2, obs2, [&](double dep) { if constexpr (TPW > 3) request(four, 3, act3, obs3, dep); });
+    }
+    if constexpr (TPW > 3) {
+        if (four) level0(3, act3, obs3, [](double) {});
+    }
+
+    // ---- camera-subset search over the pooled units; their results are patched over what their tiles stored --------------
+    if (n_used > 0) {
+        __builtin_amdgcn_s_waitcnt(0);                                     // the tiles' stores have been written
+        flush();
+    }
+
+    if (a.stats && lane == 0) {
+        unsigned long long *st = a.stats + (size_t)(blockIdx.x % P2S_STAT_SHARDS) * P2S_STAT_STRIDE;
+        if (st_units) atomicAdd(st + 0, (unsigned long long)st_units);
+        if (st_evals) atomicAdd(st + 1, (unsigned long long)st_evals);
+        if (st_passes) atomicAdd(st + 2, (unsigned long long)st_passes);
+        if (st_screened) atomicAdd(st + 6, (unsigned long long)st_screened);
+        if (st_spasses) atomicAdd(st + 7, (unsigned long long)st_spasses);
+    }
+}
+
+}  // namespace
+
+namespace {
+
+template <typename T, int CT, int NSLOT, int TPW>
+hipError_t launch_pool(P2sTriArgs a, int singles_pct, hipStream_t s) {
+    const int64_t n_units = a.n_blocks * a.K;
+    const int64_t n_tiles = (n_units + 63) / 64;
+    const int64_t per_xcd = (n_tiles + 7) / 8;
+    int64_t singles = per_xcd * singles_pct / 100;
+    singles += (per_xcd - singles) % TPW;                      // the rest in whole groups of TPW
+    a.pool_singles = (uint32_t)singles;
+    a.pool_pairs = (uint32_t)((per_xcd - singles) / TPW);
+    const unsigned grid = (unsigned)(8 * (a.pool_pairs + a.pool_singles));
+    if (a.C == CT)
+        hipLaunchKernelGGL((p2s_tri_pool_kernel<T, CT, NSLOT, true, TPW>), dim3(grid), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((p2s_tri_pool_kernel<T, CT, NSLOT, false, TPW>), dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool p2s_tri_pool_supports(int C, int dtype, int undistort, int lr_swap) {
+    if (undistort || lr_swap) return false;
+    return dtype == 0 ? C <= 8 : false;
+}
+
+hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int dtype, int singles_pct, int tiles_per_wave, hipStream_t s) {
+    (void)dtype;
+    if (a.C <= 4) return launch_pool<float, 4, 32, 3>(a, singles_pct, s);
+    if (tiles_per_wave == 2) return launch_pool<float, 8, 32, 2>(a, singles_pct, s);
+    if (tiles_per_wave == 4) return launch_pool<float, 8, 32, 4>(a, singles_pct, s);
+    return launch_pool<float, 8, 32, 3>(a, singles_pct, s);
+}

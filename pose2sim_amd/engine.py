@@ -89,17 +89,19 @@ class Engine:
 
     # p2s_set_tuning keys (include/p2s.h): experiments and tests only, results never depend on them
     TUNE_TRI_PATH, TUNE_FORCE_TILED, TUNE_NO_OVERLAP, TUNE_SEARCH_JOB, TUNE_DIAG_MODE, TUNE_MAX_SUBSETS, TUNE_DEEP_MIN_SUBSETS = 1, 2, 3, 4, 5, 6, 7
-    TUNE_ASSOC_FORM, TUNE_POOL_SINGLES_PCT, TUNE_DEEP_PRUNE = 8, 9, 10
-    TRI_PATH_AUTO, TRI_PATH_WORKLIST, TRI_PATH_ONE_TILE = 0, 1, 2
+    TUNE_ASSOC_FORM, TUNE_POOL_SINGLES_PCT, TUNE_DEEP_PRUNE, TUNE_SCREEN, TUNE_POOL_TILES = 8, 9, 10, 11, 12
+    TRI_PATH_AUTO, TRI_PATH_WORKLIST, TRI_PATH_ONE_TILE, TRI_PATH_POOLED, TRI_PATH_TWO_TILES = 0, 1, 2, 3, 4
     ASSOC_FORM_AUTO, ASSOC_FORM_GENERAL = 0, 1
 
     def tri_stats(self, reset=False):
         """Counters of this engine's triangulation calls: units that entered the camera-subset search, subsets
-        evaluated, 64-lane evaluation passes, units stopped by the 2^26-subsets-per-level safety valve."""
-        out = np.zeros(6, dtype=np.uint64)
+        evaluated (fp64), 64-lane evaluation passes, units stopped by the 2^26-subsets-per-level safety valve, the pruned
+        passes' per-camera errors and candidates, subsets looked at by the pooled kernel's fp32 screen and its passes."""
+        out = np.zeros(8, dtype=np.uint64)
         _lib.check(self._lib.p2s_get_tri_stats(self._h, _ptr(out), 1 if reset else 0))
         return {'search_units': int(out[0]), 'subsets_evaluated': int(out[1]), 'passes': int(out[2]), 'capped_units': int(out[3]),
-                'pruned_camera_errors': int(out[4]), 'pruned_subsets': int(out[5])}
+                'pruned_camera_errors': int(out[4]), 'pruned_subsets': int(out[5]),
+                'screened_subsets': int(out[6]), 'screen_passes': int(out[7])}
 
     def assoc_stats(self, reset=False):
         """Counters of this engine's multi-person association calls: frames with detections, ADMM passes, Jacobi sweeps,

@@ -23,14 +23,20 @@ FAR_M = 100.0
 TOL_E = 2e-6        # px, relative to max(1, err)
 
 
-@pytest.fixture(scope='module', params=['auto', 'worklist', 'onetile'])
+@pytest.fixture(scope='module', params=['auto', 'worklist', 'onetile', 'twotiles', 'noscreen'])
 def engine(request):
+    """auto: the pooled kernel (persistent waves, fp32 screen + fp64 evaluation of the survivors) where it applies, else the
+    one-launch kernel, else the work-list pair; noscreen: the pooled kernel with every candidate sent to the fp64
+    evaluation; twotiles / onetile: the one-launch kernel of round 2; worklist: the pair everywhere."""
     import __graft_entry__ as entry
     entry.build_hip()
     from pose2sim_amd.engine import Engine
     eng = Engine(0)
     eng.set_tuning(Engine.TUNE_TRI_PATH, {'auto': Engine.TRI_PATH_AUTO, 'worklist': Engine.TRI_PATH_WORKLIST,
-                                          'onetile': Engine.TRI_PATH_ONE_TILE}[request.param])
+                                          'onetile': Engine.TRI_PATH_ONE_TILE, 'twotiles': Engine.TRI_PATH_TWO_TILES,
+                                          'noscreen': Engine.TRI_PATH_POOLED}[request.param])
+    if request.param == 'noscreen':
+        eng.set_tuning(Engine.TUNE_SCREEN, 0)
     yield eng
     eng.close()
 
