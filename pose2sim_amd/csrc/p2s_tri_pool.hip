@@ -88,39 +88,47 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- tier A arithmetic (fp32) ---------------------------------------------------------------------------------------
-// q = (M - lam I)^-1 r through the adjugate; det and trace of M - lam I for the conditioning guard.
-struct Sym3f { float m00, m01, m02, m11, m12, m22; };
+// ---- tier A arithmetic (fp32, TWO candidates per lane in the halves of packed registers) ---------------------------------
+// A wave64 v_pk_fma_f32 does two FMAs per lane in ~4.5 cycles of its SIMD against ~2.9 for one v_fma_f32
+// (exp/valu_rates.hip), and everything that is not arithmetic -- observations and projection matrices fetched, loop and
+// mask bookkeeping -- is paid once for the two.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f rcp2(v2f a) { return v2f{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f rsq2(v2f a) { return v2f{__builtin_amdgcn_rsqf(a.x), __builtin_amdgcn_rsqf(a.y)}; }
+struct Sym3v { v2f m00, m01, m02, m11, m12, m22; };
 
-__device__ __forceinline__ void solve3f(const Sym3f &M, float lam, float r0, float r1, float r2, float &q0, float &q1, float &q2,
-                                        float &det, float &tr, bool &pd) {
-    const float a00 = M.m00 - lam, a11 = M.m11 - lam, a22 = M.m22 - lam;
-    const float c00 = fmaf(a11, a22, -M.m12 * M.m12);
-    const float c01 = fmaf(M.m02, M.m12, -M.m01 * a22);
-    const float c02 = fmaf(M.m01, M.m12, -M.m02 * a11);
-    const float c11 = fmaf(a00, a22, -M.m02 * M.m02);
-    const float c12 = fmaf(M.m01, M.m02, -a00 * M.m12);
-    const float c22 = fmaf(a00, a11, -M.m01 * M.m01);
-    det = fmaf(a00, c00, fmaf(M.m01, c01, M.m02 * c02));
-    const float id = __builtin_amdgcn_rcpf(det);
-    q0 = fmaf(c00, r0, fmaf(c01, r1, c02 * r2)) * id;
-    q1 = fmaf(c01, r0, fmaf(c11, r1, c12 * r2)) * id;
-    q2 = fmaf(c02, r0, fmaf(c12, r1, c22 * r2)) * id;
+// q = (M - lam I)^-1 r through the adjugate; det and trace of M - lam I for the conditioning guard.
+__device__ __forceinline__ void solve3v(const Sym3v &M, v2f lam, v2f r0, v2f r1, v2f r2, v2f &q0, v2f &q1, v2f &q2, v2f &det,
+                                        v2f &tr, v2f &a00, v2f &c22) {
+    a00 = M.m00 - lam;
+    const v2f a11 = M.m11 - lam, a22 = M.m22 - lam;
+    const v2f c00 = fma2(a11, a22, -M.m12 * M.m12);
+    const v2f c01 = fma2(M.m02, M.m12, -M.m01 * a22);
+    const v2f c02 = fma2(M.m01, M.m12, -M.m02 * a11);
+    const v2f c11 = fma2(a00, a22, -M.m02 * M.m02);
+    const v2f c12 = fma2(M.m01, M.m02, -a00 * M.m12);
+    c22 = fma2(a00, a11, -M.m01 * M.m01);
+    det = fma2(a00, c00, fma2(M.m01, c01, M.m02 * c02));
+    const v2f id = rcp2(det);
+    q0 = fma2(c00, r0, fma2(c01, r1, c02 * r2)) * id;
+    q1 = fma2(c01, r0, fma2(c11, r1, c12 * r2)) * id;
+    q2 = fma2(c02, r0, fma2(c12, r1, c22 * r2)) * id;
     tr = a00 + a11 + a22;
-    pd = (a00 > 0.0f) && (c22 > 0.0f) && (det > 0.0f);
 }
 
 // Rayleigh quotient of v = (q, 1) for the pencil (N', G) of the shifted problem: N' = [[M, g], [g^T, h]],
 // G = T^T T with T the translation by c0, i.e. v^T G v = |c0 + q|^2 + 1.
-__device__ __forceinline__ float rayleighf(const Sym3f &M, float g0, float g1, float g2, float h, float c0, float c1, float c2,
-                                           float q0, float q1, float q2) {
-    const float t0 = fmaf(M.m00, q0, fmaf(M.m01, q1, M.m02 * q2));
-    const float t1 = fmaf(M.m01, q0, fmaf(M.m11, q1, M.m12 * q2));
-    const float t2 = fmaf(M.m02, q0, fmaf(M.m12, q1, M.m22 * q2));
-    const float num = fmaf(q0, fmaf(2.0f, g0, t0), fmaf(q1, fmaf(2.0f, g1, t1), fmaf(q2, fmaf(2.0f, g2, t2), h)));
-    const float Q0 = c0 + q0, Q1 = c1 + q1, Q2 = c2 + q2;
-    const float den = fmaf(Q0, Q0, fmaf(Q1, Q1, fmaf(Q2, Q2, 1.0f)));
-    return num * __builtin_amdgcn_rcpf(den);
+__device__ __forceinline__ v2f rayleighv(const Sym3v &M, v2f g0, v2f g1, v2f g2, v2f h, v2f c0, v2f c1, v2f c2, v2f q0, v2f q1, v2f q2) {
+    const v2f t0 = fma2(M.m00, q0, fma2(M.m01, q1, M.m02 * q2));
+    const v2f t1 = fma2(M.m01, q0, fma2(M.m11, q1, M.m12 * q2));
+    const v2f t2 = fma2(M.m02, q0, fma2(M.m12, q1, M.m22 * q2));
+    const v2f two = splat2(2.0f);
+    const v2f num = fma2(q0, fma2(two, g0, t0), fma2(q1, fma2(two, g1, t1), fma2(q2, fma2(two, g2, t2), h)));
+    const v2f Q0 = c0 + q0, Q1 = c1 + q1, Q2 = c2 + q2;
+    const v2f den = fma2(Q0, Q0, fma2(Q1, Q1, fma2(Q2, Q2, splat2(1.0f))));
+    return num * rcp2(den);
 }
 
 // The screen's margin and guards (exp/screen_proto.py): with det / tr^3 >= 3e-3 (condition number of M - lam I below
@@ -143,8 +151,8 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
     uint32_t *sE = reinterpret_cast<uint32_t *>(sShare + 1536);
     uint32_t *sM = reinterpret_cast<uint32_t *>(sShare + 1792);
     uint8_t *sX = sShare + 2048;
-    uint2 *sSurv = reinterpret_cast<uint2 *>(sShare);    // 128 entries: {slot | subset << 8, rank}
-    uint32_t *sList = reinterpret_cast<uint32_t *>(sShare + 1024);
+    uint2 *sSurv = reinterpret_cast<uint2 *>(sShare);    // 192 entries: {slot | subset << 8, rank}
+    uint32_t *sList = reinterpret_cast<uint32_t *>(sShare + 1536);
 
     const int C = EXACT ? CT : a.C;
     const int K = a.K;
@@ -273,11 +281,13 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     wsync();
                     if (first && s.rank == r) { s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2]; s.S = S; }
                     st_evals += n; ++st_passes;
-                    // what is left of the list moves to its head (at most 63 entries)
+                    // what is left of the list moves to its head (at most 127 entries)
                     const uint32_t rem = nSurv - n;
-                    const uint2 mv = sSurv[((uint32_t)lane < rem) ? 64 + lane : 0];
+                    const uint2 mv0 = sSurv[((uint32_t)lane < rem) ? 64 + lane : 0];
+                    const uint2 mv1 = sSurv[((uint32_t)lane + 64u < rem) ? 128 + lane : 0];
                     wsync();
-                    if ((uint32_t)lane < rem) sSurv[lane] = mv;
+                    if ((uint32_t)lane < rem) sSurv[lane] = mv0;
+                    if ((uint32_t)lane + 64u < rem) sSurv[64 + lane] = mv1;
                     nSurv = rem;
                     wsync();
                 }
@@ -311,9 +321,9 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     nsub = a.sub_off[level + 1] - sub0;
                     {
                         uint32_t best_cost = 0xffffffffu;
-                        for (int l = 2; l <= 6; ++l) {
+                        for (int l = 1; l <= 6; ++l) {                              // 2^l lanes per unit, two subsets per lane
                             const uint32_t passes = (((uint32_t)npend << l) + 63u) >> 6;
-                            const uint32_t rounds = (nsub + (1u << l) - 1u) >> l;
+                            const uint32_t rounds = (nsub + (2u << l) - 1u) >> (l + 1);
                             const uint32_t cost = passes * rounds;
                             if (cost <= best_cost) { best_cost = cost; lg = l; }
                         }
@@ -322,7 +332,8 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     phase = PH_ROUND;
                     continue;
                 }
-                // ---- tier A: one round of the screen; lane j of a group looks at subset #(r0 + j) of its unit's level ----
+                // ---- tier A: one round of the screen; lane j of a group looks at subsets #(r0 + j) and #(r0 + G + j) of its
+                // unit's level, one in each half of its packed registers
                 {
                     const int G = 1 << lg, groups = 64 >> lg;
                     const int grp = lane >> lg, lig = lane & (G - 1);
@@ -331,97 +342,117 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     slot_t &s = slots[si];
                     const uint32_t o_d = s.nan | s.zero, o_valid = allmask & ~o_d;
                     const bool last = level >= C - a.min_cams - __popc(o_d);         // the unit's last level: its minimum counts whatever it is
-                    const uint32_t r = r0 + (uint32_t)lig;
-                    bool go = has && (r < nsub);
-                    uint32_t S = 0;
-                    if (go) {
-                        // level 1 is rank r <-> camera r (itertools.combinations order); the deeper levels go to the table
-                        S = (level == 1) ? (1u << r) : (uint32_t)a.sub_tab[sub0 + r];
-                        // quirk Q1 duplicates: only the lexicographically first padding can win the argmin
-                        const uint32_t pad = S & o_d;
-                        const uint32_t below = pad ? ((2u << (31 - __builtin_clz(pad))) - 1u) : 0u;
-                        go = (o_d & below) == pad;
-                    }
-                    if (__any(go)) {
-                        const uint32_t Rreal = S & o_valid, kept = o_valid & ~Rreal;
-                        const int nkept = __popc(kept);
-                        float e_lo = -kInfF, e_hi = kInfF;
+                    const uint32_t rA = r0 + (uint32_t)lig, rB = rA + (uint32_t)G;
+                    auto subset_of = [&](const uint32_t r, bool &go) -> uint32_t {
+                        uint32_t S = 0;
+                        go = has && (r < nsub);
+                        if (go) {
+                            // level 1 is rank r <-> camera r (itertools.combinations order); the deeper levels go to the table
+                            S = (level == 1) ? (1u << r) : (uint32_t)a.sub_tab[sub0 + r];
+                            // quirk Q1 duplicates: only the lexicographically first padding can win the argmin
+                            const uint32_t pad = S & o_d;
+                            const uint32_t below = pad ? ((2u << (31 - __builtin_clz(pad))) - 1u) : 0u;
+                            go = (o_d & below) == pad;
+                        }
+                        return S;
+                    };
+                    bool goA, goB;
+                    const uint32_t SA = subset_of(rA, goA), SB = subset_of(rB, goB);
+                    if (__any(goA || goB)) {
+                        const uint32_t RA = SA & o_valid, RB = SB & o_valid;
+                        const uint32_t keptA = o_valid & ~RA, keptB = o_valid & ~RB;
+                        const int nkA = __popc(keptA), nkB = __popc(keptB);
+                        float loA = -kInfF, hiA = kInfF, loB = -kInfF, hiB = kInfF;
                         if (screen_on) {
-                            Sym3f M{s.M[0], s.M[1], s.M[2], s.M[3], s.M[4], s.M[5]};
-                            float g0 = s.g[0], g1 = s.g[1], g2 = s.g[2], h = s.h;
                             const float c0 = s.c0[0], c1 = s.c0[1], c2 = s.c0[2];
-                            for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
-                                const bool on = rr != 0u;
-                                const int c = on ? __builtin_ctz(rr) : 0;
-                                const float x = on ? (float)s.o[3 * c] : 0.0f, y = on ? (float)s.o[3 * c + 1] : 0.0f;
-                                const float w = on ? (float)s.o[3 * c + 2] : 0.0f;
-                                const float *P = sPf + c * 12;
-                                const float A0 = fmaf(-x, P[8], P[0]), A1 = fmaf(-x, P[9], P[1]), A2 = fmaf(-x, P[10], P[2]), A3 = fmaf(-x, P[11], P[3]);
-                                const float B0 = fmaf(-y, P[8], P[4]), B1 = fmaf(-y, P[9], P[5]), B2 = fmaf(-y, P[10], P[6]), B3 = fmaf(-y, P[11], P[7]);
-                                const float u = fmaf(A0, c0, fmaf(A1, c1, fmaf(A2, c2, A3)));
-                                const float v = fmaf(B0, c0, fmaf(B1, c1, fmaf(B2, c2, B3)));
-                                const float w2 = w * w;
-                                const float a0 = A0 * w2, a1 = A1 * w2, a2 = A2 * w2, b0 = B0 * w2, b1 = B1 * w2, b2 = B2 * w2;
-                                M.m00 = fmaf(-a0, A0, fmaf(-b0, B0, M.m00)); M.m01 = fmaf(-a0, A1, fmaf(-b0, B1, M.m01));
-                                M.m02 = fmaf(-a0, A2, fmaf(-b0, B2, M.m02)); M.m11 = fmaf(-a1, A1, fmaf(-b1, B1, M.m11));
-                                M.m12 = fmaf(-a1, A2, fmaf(-b1, B2, M.m12)); M.m22 = fmaf(-a2, A2, fmaf(-b2, B2, M.m22));
-                                g0 = fmaf(-a0, u, fmaf(-b0, v, g0)); g1 = fmaf(-a1, u, fmaf(-b1, v, g1)); g2 = fmaf(-a2, u, fmaf(-b2, v, g2));
-                                h = fmaf(-w2 * u, u, fmaf(-w2 * v, v, h));
-                            }
+                            // the removed cameras leave the normal matrix: each half walks its own subset
+                            struct Base { float m00, m01, m02, m11, m12, m22, g0, g1, g2, h; };
+                            const Base base{s.M[0], s.M[1], s.M[2], s.M[3], s.M[4], s.M[5], s.g[0], s.g[1], s.g[2], s.h};
+                            auto downdate = [&](const bool go, const uint32_t Rreal) -> Base {
+                                Base b = base;
+                                for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                                    const bool on = rr != 0u;
+                                    const int c = on ? __builtin_ctz(rr) : 0;
+                                    const float x = on ? (float)s.o[3 * c] : 0.0f, y = on ? (float)s.o[3 * c + 1] : 0.0f;
+                                    const float w = on ? (float)s.o[3 * c + 2] : 0.0f;
+                                    const float *P = sPf + c * 12;
+                                    const float A0 = fmaf(-x, P[8], P[0]), A1 = fmaf(-x, P[9], P[1]), A2 = fmaf(-x, P[10], P[2]), A3 = fmaf(-x, P[11], P[3]);
+                                    const float B0 = fmaf(-y, P[8], P[4]), B1 = fmaf(-y, P[9], P[5]), B2 = fmaf(-y, P[10], P[6]), B3 = fmaf(-y, P[11], P[7]);
+                                    const float u = fmaf(A0, c0, fmaf(A1, c1, fmaf(A2, c2, A3)));
+                                    const float v = fmaf(B0, c0, fmaf(B1, c1, fmaf(B2, c2, B3)));
+                                    const float w2 = w * w;
+                                    const float a0 = A0 * w2, a1 = A1 * w2, a2 = A2 * w2, b0 = B0 * w2, b1 = B1 * w2, b2 = B2 * w2;
+                                    b.m00 = fmaf(-a0, A0, fmaf(-b0, B0, b.m00)); b.m01 = fmaf(-a0, A1, fmaf(-b0, B1, b.m01));
+                                    b.m02 = fmaf(-a0, A2, fmaf(-b0, B2, b.m02)); b.m11 = fmaf(-a1, A1, fmaf(-b1, B1, b.m11));
+                                    b.m12 = fmaf(-a1, A2, fmaf(-b1, B2, b.m12)); b.m22 = fmaf(-a2, A2, fmaf(-b2, B2, b.m22));
+                                    b.g0 = fmaf(-a0, u, fmaf(-b0, v, b.g0)); b.g1 = fmaf(-a1, u, fmaf(-b1, v, b.g1)); b.g2 = fmaf(-a2, u, fmaf(-b2, v, b.g2));
+                                    b.h = fmaf(-w2 * u, u, fmaf(-w2 * v, v, b.h));
+                                }
+                                return b;
+                            };
+                            const Base bA = downdate(goA, RA), bB = downdate(goB, RB);
+                            const Sym3v M{v2f{bA.m00, bB.m00}, v2f{bA.m01, bB.m01}, v2f{bA.m02, bB.m02}, v2f{bA.m11, bB.m11}, v2f{bA.m12, bB.m12}, v2f{bA.m22, bB.m22}};
+                            const v2f g0{bA.g0, bB.g0}, g1{bA.g1, bB.g1}, g2{bA.g2, bB.g2}, h{bA.h, bB.h};
                             // smallest eigenpair of the pencil: (M - lam) q = lam c0 - g, lam = Rayleigh quotient; from
                             // lam = 0 (the inhomogeneous least-squares point) two steps leave |dlam / lam| ~ 1e-4 or less
-                            float q0, q1, q2, det, tr;
-                            bool pd;
-                            solve3f(M, 0.0f, -g0, -g1, -g2, q0, q1, q2, det, tr, pd);
-                            const float lam1 = rayleighf(M, g0, g1, g2, h, c0, c1, c2, q0, q1, q2);
-                            solve3f(M, lam1, fmaf(lam1, c0, -g0), fmaf(lam1, c1, -g1), fmaf(lam1, c2, -g2), q0, q1, q2, det, tr, pd);
-                            const float lam2 = rayleighf(M, g0, g1, g2, h, c0, c1, c2, q0, q1, q2);
-                            solve3f(M, lam2, fmaf(lam2, c0, -g0), fmaf(lam2, c1, -g1), fmaf(lam2, c2, -g2), q0, q1, q2, det, tr, pd);
-                            const float dlam = fabsf(lam2 - lam1) * __builtin_amdgcn_rcpf(fabsf(lam2));
-                            const float Q0 = c0 + q0, Q1 = c1 + q1, Q2 = c2 + q2;
-                            // mean reprojection error of the kept cameras, |(a/z - x, b/z - y)| = s / sqrt(s z^2)
-                            float sum = 0.0f;
-                            bool regular = true;
+                            const v2f cc0 = splat2(c0), cc1 = splat2(c1), cc2 = splat2(c2);
+                            v2f q0, q1, q2, det, tr, a00, c22;
+                            solve3v(M, splat2(0.0f), -g0, -g1, -g2, q0, q1, q2, det, tr, a00, c22);
+                            const v2f lam1 = rayleighv(M, g0, g1, g2, h, cc0, cc1, cc2, q0, q1, q2);
+                            solve3v(M, lam1, fma2(lam1, cc0, -g0), fma2(lam1, cc1, -g1), fma2(lam1, cc2, -g2), q0, q1, q2, det, tr, a00, c22);
+                            const v2f lam2 = rayleighv(M, g0, g1, g2, h, cc0, cc1, cc2, q0, q1, q2);
+                            solve3v(M, lam2, fma2(lam2, cc0, -g0), fma2(lam2, cc1, -g1), fma2(lam2, cc2, -g2), q0, q1, q2, det, tr, a00, c22);
+                            const v2f dl = (lam2 - lam1) * rcp2(lam2);
+                            const float dlamA = fabsf(dl.x), dlamB = fabsf(dl.y);
+                            const v2f Q0 = cc0 + q0, Q1 = cc1 + q1, Q2 = cc2 + q2;
+                            // mean reprojection error of the kept cameras, |(a/z - x, b/z - y)| = s / sqrt(s z^2); a camera that is
+                            // not kept adds +0 whatever it computes, a kept one that is degenerate leaves NaN or inf in the sum
+                            v2f sum = splat2(0.0f);
                             cam_cptr cams_here = cams;
                             asm volatile("" : "+s"(cams_here));
                             for_each_cam<CT>(C, [&](int c) {
                                 const __attribute__((address_space(4))) float *P = cams_here[c].Pf;
                                 const float x = (float)s.o[3 * c], y = (float)s.o[3 * c + 1];
-                                const float pa = fmaf(P[0], Q0, fmaf(P[1], Q1, P[2] * Q2)) + P[3];
-                                const float pb = fmaf(P[4], Q0, fmaf(P[5], Q1, P[6] * Q2)) + P[7];
-                                const float pz = fmaf(P[8], Q0, fmaf(P[9], Q1, P[10] * Q2)) + P[11];
-                                const float du = fmaf(-x, pz, pa), dv = fmaf(-y, pz, pb);
-                                const float ss = fmaf(du, du, dv * dv);
-                                const float t = ss * pz * pz;
-                                const bool k = (kept >> c) & 1u;
-                                regular = regular && (!k || ((t > 0.0f) && (t < kInfF) && (pz > 0.0f)));
-                                const float d = ss * __builtin_amdgcn_rsqf(t);
-                                sum += k ? d : 0.0f;
+                                const v2f pa = fma2(splat2(P[0]), Q0, fma2(splat2(P[1]), Q1, splat2(P[2]) * Q2)) + splat2(P[3]);
+                                const v2f pb = fma2(splat2(P[4]), Q0, fma2(splat2(P[5]), Q1, splat2(P[6]) * Q2)) + splat2(P[7]);
+                                const v2f pz = fma2(splat2(P[8]), Q0, fma2(splat2(P[9]), Q1, splat2(P[10]) * Q2)) + splat2(P[11]);
+                                const v2f du = fma2(splat2(-x), pz, pa), dv = fma2(splat2(-y), pz, pb);
+                                const v2f ss = fma2(du, du, dv * dv);
+                                const v2f d = ss * rsq2(ss * pz * pz);
+                                const uint32_t mA = 0u - ((keptA >> c) & 1u), mB = 0u - ((keptB >> c) & 1u);
+                                sum.x += __uint_as_float(__float_as_uint(d.x) & mA);
+                                sum.y += __uint_as_float(__float_as_uint(d.y) & mB);
                             });
-                            const float e32 = sum * __builtin_amdgcn_rcpf((float)nkept);
-                            const bool guarded = pd && regular && (nkept >= 2) && (det >= kCondMin * tr * tr * tr) && (dlam <= kDlamMax) &&
-                                                 (e32 < kInfF);                       // false for NaN anywhere above
-                            const float marg = fmaf(e32, fmaf(kMargDlam, dlam, kMargRel), kMargAbs);
-                            e_lo = guarded ? e32 - marg : -kInfF;
-                            e_hi = guarded ? e32 + marg : kInfF;
+                            const v2f e32 = sum * rcp2(v2f{(float)nkA, (float)nkB});
+                            const v2f cond_lim = splat2(kCondMin) * tr * tr * tr;
+                            const v2f marg = fma2(e32, fma2(splat2(kMargDlam), v2f{dlamA, dlamB}, splat2(kMargRel)), splat2(kMargAbs));
+                            // (every comparison is false for a NaN: anything that went wrong above leaves the candidate unvouched)
+                            const bool gA = (a00.x > 0.0f) && (c22.x > 0.0f) && (det.x > 0.0f) && (nkA >= 2) && (det.x >= cond_lim.x) &&
+                                            (dlamA <= kDlamMax) && (e32.x < kInfF);
+                            const bool gB = (a00.y > 0.0f) && (c22.y > 0.0f) && (det.y > 0.0f) && (nkB >= 2) && (det.y >= cond_lim.y) &&
+                                            (dlamB <= kDlamMax) && (e32.y < kInfF);
+                            loA = gA ? e32.x - marg.x : -kInfF; hiA = gA ? e32.x + marg.x : kInfF;
+                            loB = gB ? e32.y - marg.y : -kInfF; hiB = gB ? e32.y + marg.y : kInfF;
                         }
-                        if (!go) { e_lo = kInfF; e_hi = kInfF; }
-                        float gmin = e_hi;
+                        if (!goA) { loA = kInfF; hiA = kInfF; }
+                        if (!goB) { loB = kInfF; hiB = kInfF; }
+                        float gmin = fminf(hiA, hiB);
                         for (int off = G >> 1; off > 0; off >>= 1) gmin = fminf(gmin, __shfl_xor(gmin, off, 64));
                         run_hi = fminf(run_hi, gmin);
                         // the true minimum w of the level has e_lo(w) <= e64(w) <= e64(S) <= e_hi(S) for every S seen so far
-                        const bool surv = go && (e_lo <= run_hi) && (last || e_lo <= thr_f);
-                        const unsigned long long sb = __ballot(surv);
-                        if (sb != 0ull) {
-                            if (surv) {
-                                sSurv[nSurv + (uint32_t)__popcll(sb & lt)] = make_uint2(si | (S << 8), r);
-                                s.surv = 1u;
-                            }
-                            nSurv += (uint32_t)__popcll(sb);
+                        const bool survA = goA && (loA <= run_hi) && (last || loA <= thr_f);
+                        const bool survB = goB && (loB <= run_hi) && (last || loB <= thr_f);
+                        const unsigned long long sbA = __ballot(survA), sbB = __ballot(survB);
+                        if ((sbA | sbB) != 0ull) {
+                            const uint32_t nA = (uint32_t)__popcll(sbA);
+                            if (survA) sSurv[nSurv + (uint32_t)__popcll(sbA & lt)] = make_uint2(si | (SA << 8), rA);
+                            if (survB) sSurv[nSurv + nA + (uint32_t)__popcll(sbB & lt)] = make_uint2(si | (SB << 8), rB);
+                            if (survA || survB) s.surv = 1u;
+                            nSurv += nA + (uint32_t)__popcll(sbB);
                         }
-                        st_screened += (uint32_t)__popcll(__ballot(go)); ++st_spasses;
+                        st_screened += (uint32_t)(__popcll(__ballot(goA)) + __popcll(__ballot(goB))); ++st_spasses;
                     }
-                    r0 += (uint32_t)G;
+                    r0 += (uint32_t)(2 * G);
                     if (r0 >= nsub) { r0 = 0; p0 += groups; run_hi = kInfF; }
                     if (p0 >= npend) {
                         // the level's screen is through: a unit nobody survived for has certainly failed the level and,

@@ -351,6 +351,51 @@ def test_pooled_search_slots_and_tile_pairing(C, p_outlier, F, singles_pct):
     _compare(Q, err, nex, mask, Qr, er, nr, mr, f'C={C} outliers {p_outlier} singles {singles_pct}%')
 
 
+@pytest.mark.parametrize('name,F,C,K,min_cams,f64,gen', [
+    ('cfg2 mix', 6_001, 8, 26, 2, False, {}),
+    ('heavy outliers', 1_500, 8, 26, 2, False, dict(p_outlier=0.30, p_lowlik=0.05, p_missing_cam=0.01)),
+    ('min_cams 4, many low-confidence', 3_000, 8, 26, 4, False, dict(p_outlier=0.08, p_lowlik=0.25)),
+    ('6 cameras', 4_000, 6, 26, 2, False, dict(p_outlier=0.10)),
+    ('4 cameras, weak geometry', 6_000, 4, 26, 2, False, dict(p_outlier=0.08, p_lowlik=0.10)),
+    ('3 cameras', 6_000, 3, 26, 2, False, dict(p_outlier=0.10)),
+    ('5 cameras x 131 keypoints', 800, 5, 131, 3, False, dict(p_outlier=0.10, p_missing_cam=0.05)),
+])
+@pytest.mark.parametrize('tiles', [2, 3, 4])
+def test_screen_changes_nothing(name, F, C, K, min_cams, f64, gen, tiles):
+    """The pooled kernel's fp32 screen decides which camera subsets reach the fp64 evaluation and nothing else: with the
+    screen off (every candidate evaluated in fp64) every output bit is the same, on seven workloads and for 2, 3 and 4
+    tiles pooled per wave -- and fewer subsets were evaluated in fp64 with it on.  Every unit against the C oracle as well."""
+    import __graft_entry__ as entry
+    entry.build_hip()
+    from oracle import tri_oracle
+    from pose2sim_amd.engine import Engine
+    from pose2sim_amd import synth
+    wl = synth.make_config(F, C, K, 1, seed=900 + C + K, **gen)
+    outs, evals = {}, {}
+    for screen in (1, 0):
+        eng = Engine(0)
+        try:
+            eng.set_tuning(Engine.TUNE_TRI_PATH, Engine.TRI_PATH_POOLED)
+            eng.set_tuning(Engine.TUNE_POOL_TILES, tiles)
+            eng.set_tuning(Engine.TUNE_SCREEN, screen)
+            eng.set_calibration(wl['P'])
+            prm = eng.tri_params(15.0, 0.3, min_cams)
+            eng.tri_stats(reset=True)
+            outs[screen] = eng.triangulate(wl['xyl'], prm)
+            evals[screen] = eng.tri_stats(reset=True)
+        finally:
+            eng.close()
+    for a, b, what in zip(outs[1], outs[0], ('Q', 'err', 'n_excl', 'mask')):
+        assert a.tobytes() == b.tobytes(), f'{name}: {what} differs between screen on and off'
+    assert evals[1]['screened_subsets'] == evals[0]['screened_subsets'] == evals[0]['subsets_evaluated']
+    if evals[0]['subsets_evaluated'] > 1000:
+        assert evals[1]['subsets_evaluated'] < 0.5 * evals[0]['subsets_evaluated'], f'{name}: the screen let {evals[1]} of {evals[0]} through'
+    threads = min(64, len(os.sched_getaffinity(0)))
+    Qr, er, nr, mr = tri_oracle.triangulate_batch(wl['xyl'].astype(np.float64), wl['P'], None, list(range(K)), 0.3, 15.0, min_cams, threads=threads)
+    _compare(*outs[1], Qr, er, nr, mr, f'{name}, {tiles} tiles')
+    print(f'{name}, {tiles} tiles: {evals[1]["subsets_evaluated"]} of {evals[0]["subsets_evaluated"]} subsets evaluated in fp64')
+
+
 @pytest.mark.parametrize('C,min_cams,lr_swap,undistort,deep_min', [(32, 24, False, False, 16384), (32, 25, True, True, 16384),
                                                                    (24, 18, True, False, 100), (20, 14, False, True, 100), (12, 3, False, False, 10)])
 def test_exact_pruning_changes_nothing(C, min_cams, lr_swap, undistort, deep_min):
