@@ -170,6 +170,24 @@ int p2s_associate_single_host(p2s_ctx *ctx, int64_t n_frames, int32_t dtype, con
  * scipy.signal.lfilter_zi(b, a); 2 <= n_coef <= 9.  All pointers are HOST pointers; the call blocks. */
 int p2s_butterworth_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_cols, const double *data, int32_t n_coef,
                          const double *b, const double *a, const double *zi, double *out);
+
+/* The other column filters of the reference's filtering stage, every column of a row-major [n_frames][n_cols] float64
+ * matrix at once (replaces Q_coords.apply(hampel_filter) and Q_coords.apply(filter1d), filtering.py:794-798):
+ *   P2S_FILTER_HAMPEL    hampel_filter filtering.py:63-85, 7-sample window; params = {n_sigma}
+ *   P2S_FILTER_GAUSSIAN  gaussian_filter_1d :513-529 = scipy.ndimage.gaussian_filter1d(col, sigma), mode 'reflect';
+ *                        params = the 2 radius + 1 kernel weights (scipy.ndimage._filters._gaussian_kernel1d)
+ *   P2S_FILTER_MEDIAN    median_filter_1d :561-577 = scipy.signal.medfilt(col, kernel_size), zero padding;
+ *                        params = {kernel_size} (odd); NaN samples are refused (scipy's result for them depends on its
+ *                        selection algorithm)
+ *   P2S_FILTER_ONE_EURO  one_euro_filter_1d :87-160, forward and backward pass over every run of >= 2 samples that are
+ *                        not NaN; params = {1 / frame_rate, min_cutoff, beta, d_cutoff}
+ * All pointers are HOST pointers; the call blocks. */
+#define P2S_FILTER_HAMPEL 1
+#define P2S_FILTER_GAUSSIAN 2
+#define P2S_FILTER_MEDIAN 3
+#define P2S_FILTER_ONE_EURO 4
+int p2s_filter_columns_host(p2s_ctx *ctx, int32_t kind, int64_t n_frames, int32_t n_cols, const double *data,
+                            const double *params, int32_t n_params, double *out);
 /* trc_evaluate's per-frame quantities and sums (Utilities/trc_evaluate.py:114-238) for xyz [n_frames][n_markers][3]:
  *   bones      [n_bones][2] int32  (parent, child) marker indices
  *   bone_len   [n_bones][n_frames]      |child - parent|, 0 -> NaN             (compute_bone_lengths :135-139)

@@ -70,6 +70,7 @@ SIGNATURES = {
     'p2s_get_tri_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'p2s_get_assoc_stats': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     'p2s_butterworth_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'p2s_filter_columns_host': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     'p2s_trc_metrics_host': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'p2s_timing_begin': (C.c_int, [C.c_void_p]),
     'p2s_timing_end': (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -829,6 +829,63 @@ int p2s_butterworth_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_cols, const d
     return P2S_OK;
 }
 
+int p2s_filter_columns_host(p2s_ctx *ctx, int32_t kind, int64_t n_frames, int32_t n_cols, const double *data,
+                            const double *params, int32_t n_params, double *out) {
+    if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");
+    if (n_frames < 0 || n_cols < 0) return fail(P2S_ERR_INVALID_ARG, "bad shape: n_frames=%lld n_cols=%d", (long long)n_frames, n_cols);
+    if (n_params < 0 || (n_params > 0 && !params)) return fail(P2S_ERR_INVALID_ARG, "null parameters");
+    P2sColFilterArgs f{};
+    f.kind = kind; f.n_frames = n_frames; f.n_cols = n_cols;
+    switch (kind) {
+    case P2S_FILTER_HAMPEL:
+        if (n_params != 1) return fail(P2S_ERR_INVALID_ARG, "Hampel filter: params = {n_sigma}");
+        f.p[0] = params[0];
+        break;
+    case P2S_FILTER_GAUSSIAN:
+        if (n_params < 1 || n_params % 2 != 1 || n_params > 8191) return fail(P2S_ERR_INVALID_ARG, "Gaussian filter: params = 2 radius + 1 weights");
+        f.radius = n_params / 2;
+        break;
+    case P2S_FILTER_MEDIAN: {
+        if (n_params != 1) return fail(P2S_ERR_INVALID_ARG, "median filter: params = {kernel_size}");
+        const int k = (int)params[0];
+        if ((double)k != params[0] || k < 1 || k % 2 != 1 || k > 1023) return fail(P2S_ERR_INVALID_ARG, "median filter: kernel_size must be odd, 1..1023");
+        f.radius = k / 2;
+        break;
+    }
+    case P2S_FILTER_ONE_EURO:
+        if (n_params != 4) return fail(P2S_ERR_INVALID_ARG, "one-euro filter: params = {dt, min_cutoff, beta, d_cutoff}");
+        for (int i = 0; i < 4; ++i) f.p[i] = params[i];
+        if (!(f.p[0] > 0.0)) return fail(P2S_ERR_INVALID_ARG, "one-euro filter: dt must be positive");
+        break;
+    default: return fail(P2S_ERR_INVALID_ARG, "unknown column filter %d", kind);
+    }
+    if (n_frames == 0 || n_cols == 0) return P2S_OK;
+    if (!data || !out) return fail(P2S_ERR_INVALID_ARG, "null pointer");
+    const size_t bytes = (size_t)n_frames * n_cols * sizeof(double);
+    if (kind == P2S_FILTER_MEDIAN)
+        for (size_t i = 0, n = (size_t)n_frames * n_cols; i < n; ++i)
+            if (!(data[i] == data[i])) return fail(P2S_ERR_INVALID_ARG, "median filter: the data hold NaN (scipy.signal.medfilt's answer for them is not defined)");
+    int rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.ensure(bytes)) != P2S_OK) return rc;
+    if ((rc = ctx->q.ensure(bytes)) != P2S_OK) return rc;
+    f.in = (const double *)ctx->in.p; f.out = (double *)ctx->q.p;
+    if (kind == P2S_FILTER_ONE_EURO) {
+        if ((rc = ctx->aux0.ensure(bytes)) != P2S_OK) return rc;
+        f.work = (double *)ctx->aux0.p;
+    }
+    if (kind == P2S_FILTER_GAUSSIAN) {
+        if ((rc = ctx->aux1.ensure((size_t)n_params * sizeof(double))) != P2S_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->aux1.p, params, (size_t)n_params * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        f.w = (const double *)ctx->aux1.p;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->in.p, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(p2s_launch_col_filter(f, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, ctx->q.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return P2S_OK;
+}
+
 int p2s_trc_metrics_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_markers, const double *xyz, int32_t n_bones,
                          const int32_t *bones, double *bone_len, double *bone_stats, double *accel, int64_t *missing) {
     if (!ctx) return fail(P2S_ERR_INVALID_ARG, "null context");

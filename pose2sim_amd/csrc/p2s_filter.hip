@@ -83,6 +83,143 @@ __global__ void __launch_bounds__(64) p2s_butter_kernel(const P2sFilterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The other column filters of filtering.py.  Hampel, Gaussian and median look at a fixed window of the INPUT around every
+// sample: one thread per (frame, column) element, consecutive threads = consecutive columns of a row (coalesced).  The
+// one-euro filter is a recurrence like the Butterworth one: one lane per column.
+
+// hampel_filter (filtering.py:63-85): 7-sample window, median and median absolute deviation; the sample is replaced by
+// the median when 0.6745 |x - median| / mad > n_sigma.  np.median of a window that holds a NaN is NaN, the comparison
+// with it is false and the sample stays; the first and last window / 2 samples are never looked at.
+__device__ __forceinline__ void sort2(double &a, double &b) { const double lo = fmin(a, b), hi = fmax(a, b); a = lo; b = hi; }
+
+__device__ __forceinline__ double median7(double v0, double v1, double v2, double v3, double v4, double v5, double v6) {
+    // the 4th smallest of 7 (no NaN among them) by a sorting network
+    sort2(v0, v4); sort2(v1, v5); sort2(v2, v6); sort2(v0, v2); sort2(v1, v3); sort2(v4, v6); sort2(v2, v4); sort2(v3, v5);
+    sort2(v0, v1); sort2(v2, v3); sort2(v4, v5); sort2(v1, v4); sort2(v3, v6); sort2(v1, v2); sort2(v3, v4); sort2(v5, v6);
+    return v3;
+}
+
+__global__ void __launch_bounds__(256) p2s_hampel_kernel(const P2sColFilterArgs a) {
+#pragma clang fp contract(off)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = a.n_frames * a.n_cols;
+    if (idx >= total) return;
+    const int64_t S = a.n_cols, f = idx / S;
+    const double x = a.in[idx];
+    double y = x;
+    if (f >= 3 && f < a.n_frames - 3) {
+        const double *p = a.in + idx;
+        const double w0 = p[-3 * S], w1 = p[-2 * S], w2 = p[-S], w4 = p[S], w5 = p[2 * S], w6 = p[3 * S];
+        const bool any_nan = !(w0 == w0) || !(w1 == w1) || !(w2 == w2) || !(x == x) || !(w4 == w4) || !(w5 == w5) || !(w6 == w6);
+        if (!any_nan) {
+            const double med = median7(w0, w1, w2, x, w4, w5, w6);
+            const double mad = median7(fabs(w0 - med), fabs(w1 - med), fabs(w2 - med), fabs(x - med), fabs(w4 - med), fabs(w5 - med),
+                                       fabs(w6 - med));
+            if (mad != 0.0) {
+                const double z = 0.6745 * (x - med) / mad;
+                if (fabs(z) > a.p[0]) y = med;
+            }
+        }
+    }
+    a.out[idx] = y;
+}
+
+// gaussian_filter_1d (filtering.py:513-529) = scipy.ndimage.correlate1d(col, weights, mode='reflect') with the weights of
+// scipy's own _gaussian_kernel1d (computed by the host with the same call): centre tap first, then the pairs from the
+// far end inwards, as scipy's loop for a symmetric kernel adds them.  A NaN spreads over its whole neighbourhood.
+__global__ void __launch_bounds__(256) p2s_gauss_kernel(const P2sColFilterArgs a) {
+#pragma clang fp contract(off)
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = a.n_frames * a.n_cols;
+    if (idx >= total) return;
+    const int64_t S = a.n_cols, F = a.n_frames, f = idx / S, c = idx - f * S;
+    const int r = a.radius;
+    auto at = [&](int64_t i) -> double {                       // 'reflect': d c b a | a b c d | d c b a
+        while (i < 0 || i >= F) i = (i < 0) ? -i - 1 : 2 * F - 1 - i;
+        return a.in[i * S + c];
+    };
+    double acc = a.in[idx] * a.w[r];
+    for (int k = -r; k < 0; ++k) acc += (at(f + k) + at(f - k)) * a.w[k + r];
+    a.out[idx] = acc;
+}
+
+// median_filter_1d (filtering.py:561-577) = scipy.signal.medfilt = ndimage.rank_filter(rank k / 2, mode='constant'): the
+// window is padded with zeros beyond the ends.  The median is the window element with as many smaller ones as its rank
+// allows (k is small: 3 to 15 in practice; windows are read through the cache).  Columns with NaN are refused by the host.
+__global__ void __launch_bounds__(256) p2s_median_kernel(const P2sColFilterArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = a.n_frames * a.n_cols;
+    if (idx >= total) return;
+    const int64_t S = a.n_cols, F = a.n_frames, f = idx / S, c = idx - f * S;
+    const int r = a.radius, want = r;                           // rank k / 2 of k = 2 r + 1
+    auto at = [&](int64_t i) -> double { return (i < 0 || i >= F) ? 0.0 : a.in[i * S + c]; };
+    double med = 0.0;
+    for (int i = -r; i <= r; ++i) {
+        const double v = at(f + i);
+        int less = 0, eq = 0;
+        for (int j = -r; j <= r; ++j) {
+            const double u = at(f + j);
+            less += (u < v) ? 1 : 0;
+            eq += (u == v) ? 1 : 0;
+        }
+        if (less <= want && want < less + eq) med = v;
+    }
+    a.out[idx] = med;
+}
+
+// one_euro_filter_1d (filtering.py:87-160): every run of at least two samples that are not NaN goes through the adaptive
+// first-order low-pass forwards, and the result through it again backwards; p = {dt, min_cutoff, beta, d_cutoff}.
+__device__ __forceinline__ double one_euro_alpha(double dt, double cutoff) {
+#pragma clang fp contract(off)
+    const double r = 2 * 3.141592653589793 * cutoff * dt;
+    return r / (r + 1);
+}
+
+__global__ void __launch_bounds__(64) p2s_one_euro_kernel(const P2sColFilterArgs a) {
+#pragma clang fp contract(off)
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= a.n_cols) return;
+    const int64_t F = a.n_frames, S = a.n_cols;
+    const double *in = a.in + col;
+    double *out = a.out + col;
+    double *work = a.work + col;
+    const double dt = a.p[0], min_cutoff = a.p[1], beta = a.p[2], d_cutoff = a.p[3];
+    const double alpha_d = one_euro_alpha(dt, d_cutoff);
+    int64_t f = 0;
+    while (f < F) {
+        const double v = in[f * S];
+        if (!(v == v)) { out[f * S] = v; ++f; continue; }
+        int64_t r = f + 1;
+        while (r < F && (in[r * S] == in[r * S])) ++r;
+        const int64_t L = r - f;
+        if (L < 2) { out[f * S] = v; f = r; continue; }
+        double x_prev = v, dx_prev = 0.0;
+        work[f * S] = v;
+        for (int64_t i = f + 1; i < r; ++i) {                  // forward pass
+            const double x = in[i * S];
+            const double dx = (x - x_prev) / dt;
+            const double dx_hat = alpha_d * dx + (1 - alpha_d) * dx_prev;
+            const double alpha = one_euro_alpha(dt, min_cutoff + beta * fabs(dx_hat));
+            const double x_hat = alpha * x + (1 - alpha) * x_prev;
+            work[i * S] = x_hat;
+            x_prev = x_hat; dx_prev = dx_hat;
+        }
+        x_prev = work[(r - 1) * S]; dx_prev = 0.0;
+        out[(r - 1) * S] = x_prev;
+        for (int64_t i = r - 2; i >= f; --i) {                 // backward pass over the forward result
+            const double x = work[i * S];
+            const double dx = (x - x_prev) / dt;
+            const double dx_hat = alpha_d * dx + (1 - alpha_d) * dx_prev;
+            const double alpha = one_euro_alpha(dt, min_cutoff + beta * fabs(dx_hat));
+            const double x_hat = alpha * x + (1 - alpha) * x_prev;
+            out[i * S] = x_hat;
+            x_prev = x_hat; dx_prev = dx_hat;
+        }
+        f = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // trc_evaluate: one workgroup per bone (blocks [0, n_bones)) or per marker (blocks [n_bones, n_bones + n_markers)).
 __global__ void __launch_bounds__(256) p2s_trc_metrics_kernel(const P2sMetricsArgs a) {
     __shared__ double s_sum[256];
@@ -169,6 +306,20 @@ hipError_t p2s_launch_butter(const P2sFilterArgs &a, hipStream_t s) {
     case 6: hipLaunchKernelGGL((p2s_butter_kernel<6>), dim3(grid), dim3(64), 0, s, a); break;
     case 7: hipLaunchKernelGGL((p2s_butter_kernel<7>), dim3(grid), dim3(64), 0, s, a); break;
     case 8: hipLaunchKernelGGL((p2s_butter_kernel<8>), dim3(grid), dim3(64), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t p2s_launch_col_filter(const P2sColFilterArgs &a, hipStream_t s) {
+    const int64_t total = a.n_frames * a.n_cols;
+    if (total == 0) return hipSuccess;
+    const unsigned grid_e = (unsigned)((total + 255) / 256), grid_c = (unsigned)((a.n_cols + 63) / 64);
+    switch (a.kind) {
+    case P2S_FILTER_HAMPEL: hipLaunchKernelGGL(p2s_hampel_kernel, dim3(grid_e), dim3(256), 0, s, a); break;
+    case P2S_FILTER_GAUSSIAN: hipLaunchKernelGGL(p2s_gauss_kernel, dim3(grid_e), dim3(256), 0, s, a); break;
+    case P2S_FILTER_MEDIAN: hipLaunchKernelGGL(p2s_median_kernel, dim3(grid_e), dim3(256), 0, s, a); break;
+    case P2S_FILTER_ONE_EURO: hipLaunchKernelGGL(p2s_one_euro_kernel, dim3(grid_c), dim3(64), 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

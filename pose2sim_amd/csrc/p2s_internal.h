@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "p2s.h"
 
 // One camera, device resident (computeP + retrieve_calib_params, common.py:254-324).
 struct P2sCam {
@@ -168,6 +169,18 @@ struct P2sFilterArgs {
     double b[P2S_MAX_FILTER_ORDER + 1], a[P2S_MAX_FILTER_ORDER + 1], zi[P2S_MAX_FILTER_ORDER];
 };
 hipError_t p2s_launch_butter(const P2sFilterArgs &a, hipStream_t s);
+
+// the window filters (Hampel, Gaussian, median) and the one-euro recurrence of filtering.py
+struct P2sColFilterArgs {
+    const double *in;            // [n_frames][n_cols]
+    double *out;                 // [n_frames][n_cols]
+    double *work;                // one-euro: forward pass [n_frames][n_cols]
+    const double *w;             // Gaussian: 2 radius + 1 weights (device)
+    int64_t n_frames;
+    int32_t n_cols, kind, radius;
+    double p[4];                 // Hampel: n_sigma; one-euro: dt, min_cutoff, beta, d_cutoff
+};
+hipError_t p2s_launch_col_filter(const P2sColFilterArgs &a, hipStream_t s);
 
 struct P2sMetricsArgs {
     const double *xyz;           // [n_frames][n_markers][3]

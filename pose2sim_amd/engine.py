@@ -206,6 +206,18 @@ class Engine:
                                                   len(b), _ptr(b), _ptr(a), _ptr(zi), _ptr(out) if out.size else None))
         return out
 
+    def filter_columns(self, kind, data, params):
+        """One of the window / recurrence filters of filtering.py on every column of data [n_frames][n_cols]
+        (include/p2s.h: P2S_FILTER_HAMPEL = 1, _GAUSSIAN = 2, _MEDIAN = 3, _ONE_EURO = 4, with their parameters)."""
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        if data.ndim != 2:
+            raise P2sError(f'data has shape {data.shape}; expected [n_frames][n_cols]')
+        params = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        out = np.empty_like(data)
+        _lib.check(self._lib.p2s_filter_columns_host(self._h, int(kind), data.shape[0], data.shape[1], _ptr(data) if data.size else None,
+                                                     _ptr(params) if params.size else None, params.size, _ptr(out) if out.size else None))
+        return out
+
     def trc_metrics(self, xyz, bones):
         """trc_evaluate's per-frame quantities for xyz [F][K][3] and bones [n][2] (parent, child marker indices):
         bone_len [n][F], bone_stats [n][3] (mean, population sd, n_valid), accel [K][F-2], missing [K]."""

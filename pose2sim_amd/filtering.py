@@ -1,11 +1,20 @@
-"""Filtering stage, Butterworth branch: mirror of Pose2Sim.filtering.filter_all for `[filtering] type = 'butterworth'`
-(filtering.py:437-471, 728-830) with the per-column filtfilt loops replaced by one call into the HIP engine
-(p2s_butterworth_host: every column of the .trc at once, one lane per column).
+"""Filtering stage: drop-in for the reference's ``filter_all(config_dict)`` (filtering.py:728-830), with the per-column
+Python loops replaced by calls into the HIP engine -- every column of the .trc at once.
 
-The coefficients come from the same SciPy calls the reference makes (scipy.signal.butter with order / 2 and
-cut_off_frequency / (frame_rate / 2); scipy.signal.lfilter_zi for filtfilt's initial state), so the kernel reproduces
-scipy.signal.filtfilt sample for sample.  The other filter types of the reference (kalman, gcv_spline, loess, ...)
-depend on packages outside the hot path's scope and are refused with NotImplementedError.
+What runs where:
+
+* outlier rejection (``reject_outliers``, hampel_filter :63-85) ............ p2s_hampel_kernel
+* ``butterworth`` (:437-471) ............................................... p2s_butter_kernel
+* ``butterworth_on_speed`` (:474-510) ...................................... first difference and running sum by pandas
+  (one vectorised call each, with the reference's fillna / cumsum semantics), the filter itself by p2s_butter_kernel
+* ``gaussian`` (:513-529) .................................................. p2s_gauss_kernel, weights from scipy's own kernel
+* ``median`` (:561-577) .................................................... p2s_median_kernel
+* ``one_euro`` (:87-160) ................................................... p2s_one_euro_kernel
+
+Coefficients and kernel weights come from the very SciPy calls the reference makes, so the kernels reproduce its numbers
+to rounding.  ``kalman``, ``gcv_spline`` and ``loess`` need filterpy / statsmodels / make_smoothing_spline, which the
+reference imports from packages that are not part of this build: they are refused with NotImplementedError.  The
+figures of the reference (``display_figures``, ``save_filt_plots``) are a GUI matter and not produced.
 """
 import glob
 import logging
@@ -15,14 +24,9 @@ import numpy as np
 
 from . import trc as trc_mod
 
-SUPPORTED_TYPES = ('butterworth',)
-
-
-def butterworth_coefficients(order, cutoff, frame_rate):
-    """(b, a, zi) exactly as filtering.py:453-457 builds them and scipy.signal.filtfilt initialises its passes."""
-    from scipy import signal
-    b, a = signal.butter(int(order) / 2, int(cutoff) / (frame_rate / 2), 'low', analog=False)
-    return np.asarray(b, dtype=np.float64), np.asarray(a, dtype=np.float64), np.asarray(signal.lfilter_zi(b, a), dtype=np.float64)
+FILTER_HAMPEL, FILTER_GAUSSIAN, FILTER_MEDIAN, FILTER_ONE_EURO = 1, 2, 3, 4          # include/p2s.h
+REFUSED_TYPES = {'kalman': 'filterpy', 'gcv_spline': 'scipy.interpolate.make_smoothing_spline and its GCV search',
+                 'loess': 'statsmodels'}
 
 
 def _make_engine():
@@ -30,13 +34,83 @@ def _make_engine():
     return Engine(int(os.environ.get('LOCAL_RANK', '0')))
 
 
+# ---- the filters, each on a whole [n_frames][n_cols] matrix -------------------------------------------------------------
+def butterworth_coefficients(order, cutoff, frame_rate):
+    """(b, a, zi) exactly as filtering.py:453-457 builds them and scipy.signal.filtfilt initialises its passes."""
+    from scipy import signal
+    b, a = signal.butter(int(order) / 2, int(cutoff) / (frame_rate / 2), 'low', analog=False)
+    return np.asarray(b, dtype=np.float64), np.asarray(a, dtype=np.float64), np.asarray(signal.lfilter_zi(b, a), dtype=np.float64)
+
+
 def butterworth_filter(data, order, cutoff, frame_rate, engine=None):
-    """Every column of data [n_frames][n_cols] through butterworth_filter_1d (filtering.py:437-471) on the GPU."""
+    """butterworth_filter_1d (filtering.py:437-471) on every column."""
     b, a, zi = butterworth_coefficients(order, cutoff, frame_rate)
     engine = engine or _make_engine()
     return engine.butterworth(np.asarray(data, dtype=np.float64), b, a, zi)
 
 
+def hampel_filter(data, engine=None, n_sigma=2.0):
+    """hampel_filter (filtering.py:63-85, window 7) on every column."""
+    engine = engine or _make_engine()
+    return engine.filter_columns(FILTER_HAMPEL, data, [float(n_sigma)])
+
+
+def butterworth_on_speed_filter(data, order, cutoff, frame_rate, engine=None):
+    """butterworth_on_speed_filter_1d (filtering.py:474-510) on every column: the speed is the first difference (its
+    missing values ALL replaced by half the second one, :494), the zero-phase filter runs over it as over positions, and
+    the running sum (NaN skipped, :508) starts again from the first position."""
+    import pandas as pd
+    frame = pd.DataFrame(np.asarray(data, dtype=np.float64))
+    speed = frame.diff()
+    if len(frame) > 1:
+        speed = speed.fillna(speed.iloc[1] / 2)
+    filtered = butterworth_filter(speed.to_numpy(), order, cutoff, frame_rate, engine)
+    return (pd.DataFrame(filtered).cumsum() + frame.iloc[0]).to_numpy()
+
+
+def gaussian_filter(data, sigma_kernel, engine=None):
+    """gaussian_filter_1d (filtering.py:513-529) on every column."""
+    from scipy.ndimage import _filters
+    sigma = int(sigma_kernel)
+    radius = int(4.0 * float(sigma) + 0.5)                     # gaussian_filter1d's truncate = 4
+    weights = np.asarray(_filters._gaussian_kernel1d(sigma, 0, radius)[::-1], dtype=np.float64)
+    engine = engine or _make_engine()
+    return engine.filter_columns(FILTER_GAUSSIAN, data, weights)
+
+
+def median_filter(data, kernel_size, engine=None):
+    """median_filter_1d (filtering.py:561-577) on every column."""
+    engine = engine or _make_engine()
+    return engine.filter_columns(FILTER_MEDIAN, data, [float(kernel_size)])
+
+
+def one_euro_filter(data, frame_rate, min_cutoff=2.5, beta=0.9, d_cutoff=1.0, engine=None):
+    """one_euro_filter_1d (filtering.py:87-160) on every column."""
+    engine = engine or _make_engine()
+    return engine.filter_columns(FILTER_ONE_EURO, data, [1.0 / frame_rate, float(min_cutoff), float(beta), float(d_cutoff)])
+
+
+def _apply(filter_type, fcfg, data, frame_rate, engine):
+    """filter1d (filtering.py:632-662) for a whole matrix."""
+    if filter_type == 'butterworth':
+        p = fcfg.get('butterworth')
+        return butterworth_filter(data, p.get('order'), p.get('cut_off_frequency'), frame_rate, engine)
+    if filter_type == 'butterworth_on_speed':
+        p = fcfg.get('butterworth_on_speed')
+        return butterworth_on_speed_filter(data, p.get('order'), p.get('cut_off_frequency'), frame_rate, engine)
+    if filter_type == 'gaussian':
+        return gaussian_filter(data, fcfg.get('gaussian').get('sigma_kernel'), engine)
+    if filter_type == 'median':
+        return median_filter(data, fcfg.get('median').get('kernel_size'), engine)
+    if filter_type == 'one_euro':
+        p = fcfg.get('one_euro')
+        return one_euro_filter(data, frame_rate, p.get('cut_off_frequency', 2.5), p.get('beta', 0.9), p.get('d_cut_off_frequency', 1.0), engine)
+    if filter_type in REFUSED_TYPES:
+        raise NotImplementedError(f"filter type '{filter_type}' needs {REFUSED_TYPES[filter_type]}, which is not part of this build")
+    raise KeyError(filter_type)                                # the reference's filter_mapping[filter_type]
+
+
+# ---- the stage ------------------------------------------------------------------------------------------------------
 def _frame_rate(config_dict, project_dir):
     """filtering.py:762-774: the configured rate, or for 'auto' the first video's (60-fps warning text, 30 fps value,
     as in the reference)."""
@@ -54,68 +128,98 @@ def _frame_rate(config_dict, project_dir):
         return 30
 
 
+def _sub(fcfg, key, default=None):
+    table = fcfg.get(key)
+    return table if isinstance(table, dict) else (default or {})
+
+
+_TYPE_LINES = {
+    'butterworth': lambda f: f"--> Filter type: Butterworth low-pass. Order {int(_sub(f, 'butterworth').get('order'))}, Cut-off frequency {int(_sub(f, 'butterworth').get('cut_off_frequency'))} Hz.",
+    'one_euro': lambda f: (f"--> Filter type: OneEuro (zero-phase). Min cutoff frequency: {_sub(f, 'one_euro').get('cut_off_frequency', 2.5)} Hz, "
+                           f"Beta: {_sub(f, 'one_euro').get('beta', 0.9)}, Derivative cutoff frequency: {_sub(f, 'one_euro').get('d_cut_off_frequency', 1.0)} Hz."),
+    'butterworth_on_speed': lambda f: (f"--> Filter type: Butterworth on speed low-pass. Order {int(_sub(f, 'butterworth_on_speed').get('order'))}, "
+                                       f"Cut-off frequency {int(_sub(f, 'butterworth_on_speed').get('cut_off_frequency'))} Hz."),
+    'gaussian': lambda f: f"--> Filter type: Gaussian. Standard deviation kernel: {int(_sub(f, 'gaussian').get('sigma_kernel'))}",
+    'median': lambda f: f"--> Filter type: Median. Kernel size: {_sub(f, 'median').get('kernel_size')}",
+}
+
+
 def recap_filter3d(config_dict, trc_path):
-    """The Butterworth lines of filtering.py:667-725."""
+    """The stage's report (filtering.py:665-725) for the filter types this build runs."""
     fcfg = config_dict.get('filtering')
-    bw = fcfg.get('butterworth')
-    lines = ['--> Outliers rejected with a Hampel filter.' if fcfg.get('reject_outliers', False)
-             else '--> No outlier rejection applied. Set reject_outliers to true in Config.toml to reject outliers.']
+    say = logging.info
+    say('--> Outliers rejected with a Hampel filter.' if fcfg.get('reject_outliers', False)
+        else '--> No outlier rejection applied. Set reject_outliers to true in Config.toml to reject outliers.')
     if fcfg.get('filter', True):
-        lines.append(f"--> Filter type: Butterworth low-pass. Order {int(bw.get('order'))}, Cut-off frequency {int(bw.get('cut_off_frequency'))} Hz.")
+        say(_TYPE_LINES[fcfg.get('type')](fcfg))
     else:
-        lines.append('--> No filtering applied. Set filtering to true in Config.toml to filter coordinates.')
-    lines.append(f'Filtered 3D coordinates are stored at {trc_path}.')
-    for line in lines:
-        logging.info(line)
+        say('--> No filtering applied. Set filtering to true in Config.toml to filter coordinates.')
+    say(f'Filtered 3D coordinates are stored at {trc_path}.')
+
+
+def _select_frames(frames_col, frame_range):
+    """filtering.py:786-792: the whole file unless frame_range lies inside it; -> (f_range, first row, one past the last)."""
+    first, last = int(frames_col.iloc[0]), int(frames_col.iloc[-1])
+    whole = frame_range in ('all', 'auto', []) or first > frame_range[0] or int(frames_col.iloc[1]) < frame_range[1]
+    f_range = [first, last + 1] if whole else frame_range
+    lo = frames_col[frames_col == f_range[0]].index[0]
+    hi = frames_col[frames_col == f_range[1] - 1].index[0] + 1
+    return f_range, lo, hi
+
+
+def _patched_header(header, name_in, name_out, frame_nb):
+    """filtering.py:795-798: the new file name in line 1, the frame count in fields 3 and 8 of line 3 (the last field
+    closes the line)."""
+    head = list(header)
+    head[0] = head[0].replace(name_in, name_out)
+    fields = head[2].split('\t')
+    fields[2] = str(frame_nb)
+    fields[7] = str(frame_nb) + '\n'
+    head[2] = '\t'.join(fields)
+    return head
 
 
 def filter_all(config_dict, engine=None):
-    """Same contract as the reference's filter_all for the Butterworth type: every `pose-3d/*.trc` without 'filt' in its
-    path -> `<name>_<f0>-<f1>_filt_butterworth.trc` with the coordinates filtered column by column."""
+    """Same contract as the reference's filter_all: every `pose-3d/*.trc` without 'filt' in its path ->
+    `<name>_<f0>-<f1>_filt_<type>.trc` with the coordinates filtered column by column.  Returns the paths written."""
     project_dir = config_dict.get('project').get('project_dir')
     pose3d_dir = os.path.realpath(os.path.join(project_dir, 'pose-3d'))
     fcfg = config_dict.get('filtering')
     do_filter = fcfg.get('filter', True)
+    reject_outliers = fcfg.get('reject_outliers', False)
     filter_type = fcfg.get('type')
     frame_range = config_dict.get('project').get('frame_range')
-    if fcfg.get('reject_outliers', False):
-        raise NotImplementedError('reject_outliers (Hampel filter) is outside the accelerated path')
-    if do_filter and filter_type not in SUPPORTED_TYPES:
-        raise NotImplementedError(f"filter type '{filter_type}' is outside the accelerated path; supported: {SUPPORTED_TYPES}")
+    if do_filter and filter_type in REFUSED_TYPES:
+        raise NotImplementedError(f"filter type '{filter_type}' needs {REFUSED_TYPES[filter_type]}, which is not part of this build; "
+                                  f"supported: {sorted(_TYPE_LINES)}")
     frame_rate = _frame_rate(config_dict, project_dir)
-    bw = fcfg.get('butterworth')
 
-    out_paths = []
-    trc_path_in = [file for file in glob.glob(os.path.join(pose3d_dir, '*.trc')) if 'filt' not in file]
-    for person_id, t_path_in in enumerate(trc_path_in):
+    written = []
+    sources = [p for p in glob.glob(os.path.join(pose3d_dir, '*.trc')) if 'filt' not in p]
+    for person_id, path_in in enumerate(sources):
         logging.info(f'\nFiltering 3D coordinates for person {person_id}...')
-        t_file_in = os.path.basename(t_path_in)
-        Q_coords, frames_col, time_col, markers, header = trc_mod.read_trc(t_path_in)
+        Q_coords, frames_col, time_col, markers, header = trc_mod.read_trc(path_in)
+        f_range, lo, hi = _select_frames(frames_col, frame_range)
+        frames = frames_col.iloc[lo:hi].to_numpy()
+        times = time_col.iloc[lo:hi].to_numpy()
+        data = Q_coords.iloc[lo:hi].to_numpy(dtype=np.float64)
+        path_out = path_in.replace(path_in.split('_')[-1], f'{f_range[0]}-{f_range[1]}_filt_{filter_type}.trc')
+        head = _patched_header(header, os.path.basename(path_in), os.path.basename(path_out), f_range[1] - f_range[0])
 
-        first, last = int(frames_col.iloc[0]), int(frames_col.iloc[-1])          # filtering.py:786-792
-        whole = frame_range in ('all', 'auto', []) or first > frame_range[0] or int(frames_col.iloc[1]) < frame_range[1]
-        f_range = [first, last + 1] if whole else frame_range
-        frame_nb = f_range[1] - f_range[0]
-        lo = frames_col[frames_col == f_range[0]].index[0]
-        hi = frames_col[frames_col == f_range[1] - 1].index[0] + 1
-        Q_coords = Q_coords.iloc[lo:hi].reset_index(drop=True)
-        frames_col = frames_col.iloc[lo:hi].reset_index(drop=True)
-        time_col = time_col.iloc[lo:hi].reset_index(drop=True)
-
-        t_path_out = t_path_in.replace(t_path_in.split('_')[-1], f'{f_range[0]}-{f_range[1]}_filt_{filter_type}.trc')
-        t_file_out = os.path.basename(t_path_out)
-        header[0] = header[0].replace(t_file_in, t_file_out)                     # :796-798
-        header[2] = '\t'.join(part if i != 2 else str(frame_nb) for i, part in enumerate(header[2].split('\t')))
-        header[2] = '\t'.join(part if i != 7 else str(frame_nb) + '\n' for i, part in enumerate(header[2].split('\t')))
-
-        if not do_filter:
-            logging.warning(f'reject_outliers and filter have been set to false. No further processing done on {t_path_in}.\n')
+        if not do_filter and not reject_outliers:
+            logging.warning(f'reject_outliers and filter have been set to false. No further processing done on {path_in}.\n')
             continue
-        data = Q_coords.to_numpy(dtype=np.float64)
-        filtered = butterworth_filter(data, bw.get('order'), bw.get('cut_off_frequency'), frame_rate, engine)
-        with open(t_path_out, 'w') as trc_o:
-            trc_o.writelines(header)
-        trc_mod.write_rows(t_path_out, frames_col.to_numpy(), time_col.to_numpy(), filtered)
-        recap_filter3d(config_dict, t_path_out)
-        out_paths.append(t_path_out)
-    return out_paths
+        if reject_outliers:
+            data = hampel_filter(data, engine)
+        if not do_filter:
+            # the reference goes on to plot and write `Q_filt`, which only the filter assigns (:804-815)
+            raise UnboundLocalError("local variable 'Q_filt' referenced before assignment")
+        filtered = _apply(filter_type, fcfg, data, frame_rate, engine)
+        with open(path_out, 'w') as fh:
+            fh.writelines(head)
+        trc_mod.write_rows(path_out, frames, times, filtered)
+        if fcfg.get('make_c3d'):
+            logging.warning('make_c3d: the c3d package is not available in this build; only the .trc file was written.')
+        recap_filter3d(config_dict, path_out)
+        written.append(path_out)
+    return written

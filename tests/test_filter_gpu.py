@@ -155,3 +155,105 @@ def test_metrics_at_trial_size(engine):
     for m in (0, 7, 25):
         want = np.linalg.norm(xyz[2:, m] - 2 * xyz[1:-1, m] + xyz[:-2, m], axis=1)
         np.testing.assert_allclose(accel[m], want, rtol=1e-15, atol=1e-18, equal_nan=True)
+
+
+# ---- the other column filters (filtering.py:63-160, 474-577) ------------------------------------------------------------
+@pytest.fixture(scope='module')
+def gold2(golden_dir):
+    return np.load(os.path.join(golden_dir, 'filter_units2.npz'))
+
+
+def test_golden_columns_of_the_other_filters(engine, gold2):
+    """48 reference columns through every kernel: Hampel and median bit for bit (they select samples), one-euro, Gaussian
+    and Butterworth-on-speed within TOL (the same operations in the same order; in practice 0 or an ulp)."""
+    from pose2sim_amd import filtering
+    g = gold2
+    for i in range(int(g['n_cols'])):
+        col = g[f'col{i}_in'].reshape(-1, 1)
+        order, cutoff, rate, sigma, ksize = (int(v) for v in g[f'col{i}_prm'])
+        mc, beta, dc = g[f'col{i}_euro']
+        assert np.array_equal(filtering.hampel_filter(col, engine)[:, 0], g[f'col{i}_hampel'], equal_nan=True), ('hampel', i)
+        _close(filtering.one_euro_filter(col, rate, mc, beta, dc, engine)[:, 0], g[f'col{i}_one_euro'], f'one_euro {i}')
+        _close(filtering.gaussian_filter(col, sigma, engine)[:, 0], g[f'col{i}_gauss'], f'gauss {i}')
+        if f'col{i}_speed' in g.files:
+            _close(filtering.butterworth_on_speed_filter(col, order, cutoff, rate, engine)[:, 0], g[f'col{i}_speed'], f'speed {i}')
+        if f'col{i}_median' in g.files:
+            assert np.array_equal(filtering.median_filter(col, ksize, engine)[:, 0], g[f'col{i}_median']), ('median', i)
+
+
+def test_other_filters_on_a_matrix_against_the_oracle(engine):
+    """20 000 frames x 156 columns with spikes, NaN and zero gaps: every kernel against the NumPy / SciPy restatement."""
+    from oracle import filtering_ref as fr
+    from pose2sim_amd import filtering
+    from pose2sim_amd._lib import P2sError
+    rng = np.random.default_rng(21)
+    F, ncol = 20_000, 156
+    t = np.arange(F)[:, None] / 60.0
+    data = 1.0 + 0.5 * np.sin(2 * np.pi * (0.5 + rng.random(ncol)) * t) + rng.normal(0, 0.01, (F, ncol))
+    spikes = rng.random((F, ncol)) < 0.01
+    data[spikes] += rng.normal(0, 0.5, int(spikes.sum()))
+    clean = data.copy()
+    data[rng.random((F, ncol)) < 0.002] = np.nan
+    data[rng.random((F, ncol)) < 0.001] = 0.0
+    for c in range(0, ncol, 7):
+        g = int(rng.integers(0, F - 400)); data[g:g + int(rng.integers(1, 400)), c] = np.nan
+    data[:, 3] = np.nan
+    cols = list(range(0, ncol, 5))                               # the oracle's Python loops: a sample of the columns
+    got = filtering.hampel_filter(data, engine)
+    for c in cols:
+        assert np.array_equal(got[:, c], fr.hampel_filter(data[:, c]), equal_nan=True), c
+    assert (got != data)[~np.isnan(data)].sum() > 1000           # it did replace spikes
+    got = filtering.one_euro_filter(data, 60, 2.5, 0.9, 1.0, engine)
+    for c in cols[:8]:
+        _close(got[:, c], fr.one_euro_filter_1d(data[:, c], 60, 2.5, 0.9, 1.0), f'one_euro column {c}')
+    for sigma in (1, 3):
+        got = filtering.gaussian_filter(data, sigma, engine)
+        for c in cols:
+            _close(got[:, c], fr.gaussian_filter_1d(data[:, c], sigma), f'gauss {sigma} column {c}')
+    got = filtering.butterworth_on_speed_filter(data, 4, 10, 60, engine)
+    for c in cols[:8]:
+        _close(got[:, c], fr.butterworth_on_speed_filter_1d(data[:, c], 4, 10, 60), f'speed column {c}')
+    for k in (3, 9, 15):
+        got = filtering.median_filter(clean, k, engine)
+        for c in cols:
+            assert np.array_equal(got[:, c], fr.median_filter_1d(clean[:, c], k)), (k, c)
+    with pytest.raises(P2sError):                                # scipy's answer for NaN depends on its selection algorithm
+        filtering.median_filter(data, 5, engine)
+    for F2 in (1, 2, 5, 6, 7, 8):                                # windows longer than the data
+        small = rng.normal(1, 0.1, (F2, 70))
+        assert np.array_equal(filtering.hampel_filter(small, engine), np.stack([fr.hampel_filter(small[:, c]) for c in range(70)], 1))
+        _close(filtering.gaussian_filter(small, 2, engine), np.stack([fr.gaussian_filter_1d(small[:, c], 2) for c in range(70)], 1), f'gauss F={F2}')
+        _close(filtering.one_euro_filter(small, 30, engine=engine), np.stack([fr.one_euro_filter_1d(small[:, c], 30) for c in range(70)], 1), f'euro F={F2}')
+
+
+def test_filter_all_with_outlier_rejection_on_the_gpu(engine, gold2):
+    """filter_all with the shipped demo configuration (reject_outliers = true + Butterworth) and the other types: the
+    reference's header lines and frame / time columns exactly, coordinates within TOL."""
+    import shutil
+    import tempfile
+    from pose2sim_amd import filtering
+    g = gold2
+    root = tempfile.mkdtemp(prefix='p2s_f2_')
+    try:
+        for i in range(int(g['n_files'])):
+            trial = os.path.join(root, f'trial{i}')
+            os.makedirs(os.path.join(trial, 'pose-3d'))
+            with open(os.path.join(trial, 'pose-3d', str(g[f'file{i}_name'])), 'w') as fh:
+                fh.write(str(g[f'file{i}_text']))
+            cfg = {'project': {'project_dir': trial, 'frame_rate': int(g[f'file{i}_rate']), 'frame_range': 'auto'}, 'pose': {'vid_img_extension': 'mp4'},
+                   'filtering': {'type': str(g[f'file{i}_type']), 'filter': True, 'reject_outliers': bool(g[f'file{i}_reject']),
+                                 'butterworth': {'order': 4, 'cut_off_frequency': 6}, 'butterworth_on_speed': {'order': 4, 'cut_off_frequency': 10},
+                                 'one_euro': {'cut_off_frequency': 2.5, 'beta': 0.9, 'd_cut_off_frequency': 1.0},
+                                 'gaussian': {'sigma_kernel': 2}, 'median': {'kernel_size': 5}}}
+            paths = filtering.filter_all(cfg, engine=engine)
+            assert [os.path.basename(p) for p in paths] == [str(g[f'file{i}_out_name'])]
+            got, want = open(paths[0]).read().split('\n'), str(g[f'file{i}_out_text']).split('\n')
+            assert got[:5] == want[:5] and len(got) == len(want)
+            for gl, wl in zip(got[5:], want[5:]):
+                gf, wf = gl.split('\t'), wl.split('\t')
+                assert gf[:2] == wf[:2] and len(gf) == len(wf)
+                a = np.array([float(v) if v else np.nan for v in gf[2:]])
+                b = np.array([float(v) if v else np.nan for v in wf[2:]])
+                _close(a, b, f'file {i} ({cfg["filtering"]["type"]})')
+    finally:
+        shutil.rmtree(root, ignore_errors=True)

@@ -29,11 +29,9 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_no_gpu_means_loud_failure():
     """Without a GPU the engine must refuse to run rather than fall back to the CPU."""
-    import torch
-    if torch.cuda.is_available():
+    if _lib.device_count() > 0:                        # asked of the library itself (torch may not see the device)
         pytest.skip('GPU present')
     from pose2sim_amd.engine import Engine
-    assert _lib.device_count() == 0
     with pytest.raises(_lib.P2sError, match='no HIP device'):
         Engine(0)
 
