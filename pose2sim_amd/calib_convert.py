@@ -1,13 +1,16 @@
-"""Qualisys .qca.txt -> calibration TOML, the converter that feeds the path from the shipped demo assets
-(SURVEY.md section 8f rank 3).  Mirrors Pose2Sim/Utilities/calib_qca_to_toml.py:59-232 (the 4-coefficient
-converter; the in-tree calibration.py one builds 4 distortion terms and then indexes a fifth, :149 vs :1527):
-video cameras only, natural order of their serials, intrinsics / 64 / binning, object-centred -> camera-centred
-pose, a rotation of pi about the camera x axis, Rodrigues vector, and the same TOML text layout.
+"""Qualisys .qca.txt -> calibration TOML: the converter that feeds the path from the shipped demo assets without lxml or
+OpenCV.  Same output text as Pose2Sim/Utilities/calib_qca_to_toml.py:59-237 (the
+4-coefficient converter; the in-tree calibration.py one builds 4 distortion terms and then indexes a fifth, :149 vs :1527).
 
-Reproduced quirk: read_qca already converts the translation from mm to m (:121-123) and
-calib_qca_to_toml_func divides by 1000 again (:233), so the translations in the file are in km; the output
-is kept identical to the reference's rather than corrected.  No lxml / OpenCV needed.
+A .qca.txt file lists every camera of the Qualisys system as one <camera> element with its field of view, intrinsics
+(in 1/64 pixel) and its pose as seen from the object (mm).  Here each video camera becomes one record; the pose is turned
+into OpenCV's camera-centred convention (transpose, then half a turn about the camera's x axis because Qualisys looks
+down -z) and the rotation into a Rodrigues vector.
+
+Kept quirk: the reference converts the translation from mm to m when reading (:121-123) and divides by 1000 again when
+writing (:233), so the translations in the file are in km; the text is kept identical to the reference's.
 """
+import math
 import re
 import xml.etree.ElementTree as ET
 
@@ -15,86 +18,80 @@ import numpy as np
 
 from . import cvmath
 
+VIDEO_MODELS = ('Miqus Video', 'Miqus Video UnderWater', 'none')
+SUBPIXEL = 64                                    # Qualisys stores intrinsics in 1/64 pixel
 
-def natural_sort_key(s):
-    return [int(c) if c.isdigit() else c.lower() for c in re.split(r'(\d+)', s)]
+# half a turn about x as the reference composes it (:152-156): cos(pi) = -1 and sin(pi) = 1.2246e-16, whose digits reach
+# the rotation vectors of the file
+_HALF_TURN_X = np.array([[1.0, 0.0, 0.0], [0.0, math.cos(math.pi), -math.sin(math.pi)], [0.0, math.sin(math.pi), math.cos(math.pi)]])
 
-
-def read_qca(qca_path, binning_factor=1):
-    """-> (C names, S sizes, D distortions[4], K 3x3, R 3x3 (by line), T [m]) of the video cameras."""
-    root = ET.parse(qca_path).getroot()
-    C, S, D, K, R, T, vid_id = [], [], [], [], [], [], []
-    for i, tag in enumerate(root.findall('cameras/camera')):
-        C.append(tag.attrib.get('serial'))
-        if tag.attrib.get('model') in ('Miqus Video', 'Miqus Video UnderWater', 'none'):
-            vid_id.append(i)
-    fov = root.findall('cameras/camera/fov_video')
-    for tag in fov:
-        w = (float(tag.attrib.get('right')) - float(tag.attrib.get('left'))) / binning_factor
-        h = (float(tag.attrib.get('bottom')) - float(tag.attrib.get('top'))) / binning_factor
-        S.append([w, h])
-    for i, tag in enumerate(root.findall('cameras/camera/intrinsic')):
-        k1 = float(tag.get('radialDistortion1')) / 64 / binning_factor
-        k2 = float(tag.get('radialDistortion2')) / 64 / binning_factor
-        p1 = float(tag.get('tangentalDistortion1')) / 64 / binning_factor
-        p2 = float(tag.get('tangentalDistortion2')) / 64 / binning_factor
-        D.append(np.array([k1, k2, p1, p2]))
-        fu = float(tag.get('focalLengthU')) / 64 / binning_factor
-        fv = float(tag.get('focalLengthV')) / 64 / binning_factor
-        cu = float(tag.get('centerPointU')) / 64 / binning_factor - float(fov[i].attrib.get('left'))
-        cv = float(tag.get('centerPointV')) / 64 / binning_factor - float(fov[i].attrib.get('top'))
-        K.append(np.array([fu, 0., cu, 0., fv, cv, 0., 0., 1.]).reshape(3, 3))
-    for tag in root.findall('cameras/camera/transform'):
-        t = [float(tag.get(k)) / 1000 for k in ('x', 'y', 'z')]
-        r = {k: float(tag.get(k)) for k in ('r11', 'r12', 'r13', 'r21', 'r22', 'r23', 'r31', 'r32', 'r33')}
-        R.append(np.array([r['r11'], r['r21'], r['r31'], r['r12'], r['r22'], r['r32'], r['r13'], r['r23'], r['r33']]).reshape(3, 3))
-        T.append(np.array(t))
-    C_vid = [C[v] for v in vid_id]
-    order = [vid_id[C_vid.index(c)] for c in sorted(C_vid, key=natural_sort_key)]
-    pick = lambda L: [L[c] for c in order]          # noqa: E731
-    return pick(C), pick(S), pick(D), pick(K), pick(R), pick(T)
+_CAMERA_TEXT = ('[cam_{n}]\n'
+                'name = "{serial}"\n'
+                'size = [ {w}, {h},]\n'
+                'matrix = [ [ {fu}, 0.0, {cu},], [ 0.0, {fv}, {cv},], [ 0.0, 0.0, 1.0,],]\n'
+                'distortions = [ {k1}, {k2}, {p1}, {p2},]\n'
+                'rotation = [ {r0}, {r1}, {r2},]\n'
+                'translation = [ {t0}, {t1}, {t2},]\n'
+                'fisheye = false\n\n')
+_TRAILER = '[metadata]\nadjusted = false\nerror = 0.0\n'
 
 
-def world_to_camera_persp(r, t):
-    """Qc = R Q + T  <->  Q = R^-1 Qc - R^-1 T."""
-    r = r.T
-    return r, -r @ t
+def natural_key(text):
+    """'cam10' after 'cam9': digit runs compare as numbers, the rest case-blind."""
+    return [int(part) if part.isdigit() else part.lower() for part in re.split(r'(\d+)', text)]
 
 
-def rotate_cam(r, t, ang_x=np.pi, ang_y=0, ang_z=0):
-    rt_h = np.block([[r, t.reshape(3, 1)], [np.zeros(3), 1]])
-    r_ax_x = np.array([1, 0, 0, 0, np.cos(ang_x), -np.sin(ang_x), 0, np.sin(ang_x), np.cos(ang_x)]).reshape(3, 3)
-    r_ax_y = np.array([np.cos(ang_y), 0, np.sin(ang_y), 0, 1, 0, -np.sin(ang_y), 0, np.cos(ang_y)]).reshape(3, 3)
-    r_ax_z = np.array([np.cos(ang_z), -np.sin(ang_z), 0, np.sin(ang_z), np.cos(ang_z), 0, 0, 0, 1]).reshape(3, 3)
-    r_ax_h = np.block([[r_ax_z @ r_ax_y @ r_ax_x, np.zeros(3).reshape(3, 1)], [np.zeros(3), 1]])
-    m = r_ax_h @ rt_h
-    return m[:3, :3], m[:3, 3]
+def _attr(element, name, scale=1.0):
+    return float(element.get(name)) / scale
 
 
-def toml_text(C, S, D, K, R, T):
-    """The text Utilities/calib_qca_to_toml.py:174-192 writes."""
-    out = []
-    for c in range(len(C)):
-        out.append(f'[cam_{c+1}]\n')
-        out.append(f'name = "{C[c]}"\n')
-        out.append(f'size = [ {S[c][0]}, {S[c][1]},]\n')
-        out.append(f'matrix = [ [ {K[c][0,0]}, 0.0, {K[c][0,2]},], [ 0.0, {K[c][1,1]}, {K[c][1,2]},], [ 0.0, 0.0, 1.0,],]\n')
-        out.append(f'distortions = [ {D[c][0]}, {D[c][1]}, {D[c][2]}, {D[c][3]},]\n')
-        out.append(f'rotation = [ {R[c][0]}, {R[c][1]}, {R[c][2]},]\n')
-        out.append(f'translation = [ {T[c][0]}, {T[c][1]}, {T[c][2]},]\n')
-        out.append('fisheye = false\n\n')
-    out.append('[metadata]\nadjusted = false\nerror = 0.0\n')
-    return ''.join(out)
+def video_cameras(qca_path, binning_factor=1):
+    """One record per video camera, in the natural order of the serial numbers: serial, size [w, h], K 3x3, dist [4],
+    R 3x3 (object-centred, as stored: the file's r_ij is column i, row j) and t [m]."""
+    cameras = []
+    for cam in ET.parse(qca_path).getroot().findall('cameras/camera'):
+        if cam.get('model') not in VIDEO_MODELS:
+            continue
+        fov, intr, pose = cam.find('fov_video'), cam.find('intrinsic'), cam.find('transform')
+        left, top = float(fov.get('left')), float(fov.get('top'))
+        px = lambda name: _attr(intr, name, SUBPIXEL) / binning_factor        # noqa: E731
+        K = np.array([[px('focalLengthU'), 0.0, px('centerPointU') - left],
+                      [0.0, px('focalLengthV'), px('centerPointV') - top],
+                      [0.0, 0.0, 1.0]])
+        cameras.append({
+            'serial': cam.get('serial'),
+            'size': [(float(fov.get('right')) - left) / binning_factor, (float(fov.get('bottom')) - top) / binning_factor],
+            'K': K,
+            'dist': np.array([px('radialDistortion1'), px('radialDistortion2'), px('tangentalDistortion1'), px('tangentalDistortion2')]),
+            'R': np.array([[_attr(pose, f'r{col}{row}') for col in (1, 2, 3)] for row in (1, 2, 3)]),
+            't': np.array([_attr(pose, axis, 1000) for axis in 'xyz']),
+        })
+    return sorted(cameras, key=lambda c: natural_key(c['serial']))
+
+
+def opencv_pose(R_obj, t_obj):
+    """Object-centred (Q = R Qc + t) -> camera-centred (Qc = R' Q + t') with the camera turned to look down +z."""
+    R_cam = R_obj.T
+    t_cam = -R_cam @ t_obj
+    return _HALF_TURN_X @ R_cam, _HALF_TURN_X @ t_cam
+
+
+def toml_text(cameras):
+    parts = []
+    for n, cam in enumerate(cameras, start=1):
+        R, t = opencv_pose(cam['R'], cam['t'])
+        rvec = np.array(cvmath.rodrigues_from_matrix(R)).flatten()
+        t = t / 1000                                       # the second division (reference :233)
+        K, d = cam['K'], cam['dist']
+        parts.append(_CAMERA_TEXT.format(n=n, serial=cam['serial'], w=cam['size'][0], h=cam['size'][1], fu=K[0, 0], cu=K[0, 2],
+                                         fv=K[1, 1], cv=K[1, 2], k1=d[0], k2=d[1], p1=d[2], p2=d[3], r0=rvec[0], r1=rvec[1], r2=rvec[2],
+                                         t0=t[0], t1=t[1], t2=t[2]))
+    return ''.join(parts) + _TRAILER
 
 
 def calib_qca_to_toml(qca_path, binning_factor=1, toml_path=None):
-    """calib_qca_to_toml_func (:195-237).  Returns the path of the written TOML."""
+    """<name>.qca.txt -> <name>.toml (or toml_path).  Returns the path written."""
     toml_path = toml_path or qca_path.replace('.qca.txt', '.toml')
-    C, S, D, K, R, T = read_qca(qca_path, int(binning_factor))
-    RT = [world_to_camera_persp(r, t) for r, t in zip(R, T)]
-    RT = [rotate_cam(r, t, ang_x=np.pi, ang_y=0, ang_z=0) for r, t in RT]
-    R = [np.array(cvmath.rodrigues_from_matrix(rt[0])).flatten() for rt in RT]
-    T = np.array([rt[1] for rt in RT]) / 1000          # second division, as in the reference (:233)
     with open(toml_path, 'w+') as fh:
-        fh.write(toml_text(C, S, D, K, R, T))
+        fh.write(toml_text(video_cameras(qca_path, int(binning_factor))))
     return toml_path

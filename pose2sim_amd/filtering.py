@@ -157,13 +157,13 @@ def recap_filter3d(config_dict, trc_path):
     say(f'Filtered 3D coordinates are stored at {trc_path}.')
 
 
-def _select_frames(frames_col, frame_range):
+def _select_frames(frames, frame_range):
     """filtering.py:786-792: the whole file unless frame_range lies inside it; -> (f_range, first row, one past the last)."""
-    first, last = int(frames_col.iloc[0]), int(frames_col.iloc[-1])
-    whole = frame_range in ('all', 'auto', []) or first > frame_range[0] or int(frames_col.iloc[1]) < frame_range[1]
+    first, last = int(frames[0]), int(frames[-1])
+    whole = frame_range in ('all', 'auto', []) or first > frame_range[0] or int(frames[1]) < frame_range[1]
     f_range = [first, last + 1] if whole else frame_range
-    lo = frames_col[frames_col == f_range[0]].index[0]
-    hi = frames_col[frames_col == f_range[1] - 1].index[0] + 1
+    lo = int(np.flatnonzero(frames == f_range[0])[0])
+    hi = int(np.flatnonzero(frames == f_range[1] - 1)[0]) + 1
     return f_range, lo, hi
 
 
@@ -198,11 +198,9 @@ def filter_all(config_dict, engine=None):
     sources = [p for p in glob.glob(os.path.join(pose3d_dir, '*.trc')) if 'filt' not in p]
     for person_id, path_in in enumerate(sources):
         logging.info(f'\nFiltering 3D coordinates for person {person_id}...')
-        Q_coords, frames_col, time_col, markers, header = trc_mod.read_trc(path_in)
-        f_range, lo, hi = _select_frames(frames_col, frame_range)
-        frames = frames_col.iloc[lo:hi].to_numpy()
-        times = time_col.iloc[lo:hi].to_numpy()
-        data = Q_coords.iloc[lo:hi].to_numpy(dtype=np.float64)
+        frames, times, data, markers, header = trc_mod.load_trc(path_in)
+        f_range, lo, hi = _select_frames(frames, frame_range)
+        frames, times, data = frames[lo:hi], times[lo:hi], data[lo:hi]
         path_out = path_in.replace(path_in.split('_')[-1], f'{f_range[0]}-{f_range[1]}_filt_{filter_type}.trc')
         head = _patched_header(header, os.path.basename(path_in), os.path.basename(path_out), f_range[1] - f_range[0])
 

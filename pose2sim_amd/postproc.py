@@ -49,40 +49,102 @@ def sort_people_sports2d(keyptpre, keypt, max_dist=None):
     return sorted_prev, sorted_keypoints, sorted_ids
 
 
-# common.py:669-712
-def interpolate_zeros_nans(col, *args):
-    """Interpolate the zeros / NaNs of a pandas column unless more than N are contiguous (common.py:669-712).
-    Same calls into scipy's interp1d as the reference (so the same numbers), with the index bookkeeping done
-    on arrays instead of Python lists: 78 columns x 100 k frames went from ~5 s to well under one."""
-    kind = None
-    if len(args) == 2:
-        N, kind = args
-    elif len(args) == 1:
-        N = np.inf
-        kind = args[0]
-    else:
-        N = np.inf
-    vals = np.asarray(col, dtype=np.float64)
-    labels = np.asarray(col.index)
-    mask = ~(np.isnan(vals) | (vals == 0))
-    if int(mask.sum()) <= 4:
-        return col
-    idx_good = labels[mask]
+def _interpolate_column(vals, labels, max_gap, kind):
+    """One column of interpolate_zeros_nans (common.py:669-712) on arrays: vals [F] with labels [F] (the frame numbers
+    interp1d sees as abscissae).  Samples that are NaN or 0 are replaced by scipy's interp1d through the others
+    ('extrapolate' beyond the ends) unless they sit in a run of more than max_gap of them; with 4 or fewer good samples
+    the column comes back untouched (None)."""
+    good = ~(np.isnan(vals) | (vals == 0))
+    if int(good.sum()) <= 4:
+        return None
     if kind is None:
-        f_interp = interpolate.interp1d(idx_good, vals[mask], kind='linear', bounds_error=False)
+        f_interp = interpolate.interp1d(labels[good], vals[good], kind='linear', bounds_error=False)
     else:
-        f_interp = interpolate.interp1d(idx_good, vals[mask], kind=kind, fill_value='extrapolate', bounds_error=False)
-    out = np.where(mask, vals, f_interp(labels))
-    # runs of consecutive bad labels longer than N go back to NaN (:704-710)
-    bad_pos = np.flatnonzero(~mask)
+        f_interp = interpolate.interp1d(labels[good], vals[good], kind=kind, fill_value='extrapolate', bounds_error=False)
+    out = np.where(good, vals, f_interp(labels))
+    bad_pos = np.flatnonzero(~good)
     if bad_pos.size:
+        # runs of consecutive bad labels longer than max_gap go back to NaN (:704-710)
         bad_labels = labels[bad_pos]
         starts = np.concatenate(([0], np.flatnonzero(np.diff(bad_labels) > 1) + 1))
         lengths = np.diff(np.concatenate((starts, [bad_pos.size])))
-        for s0, ln in zip(starts[lengths > N], lengths[lengths > N]):
+        for s0, ln in zip(starts[lengths > max_gap], lengths[lengths > max_gap]):
             out[bad_pos[s0:s0 + ln]] = np.nan
+    return out
+
+
+def interpolate_zeros_nans(col, *args):
+    """The reference's per-column entry (common.py:669-712) for a pandas column: args = (N, kind) | (kind,) | ()."""
     import pandas as pd
-    return pd.Series(out, index=col.index, name=getattr(col, 'name', None))
+    max_gap, kind = (args if len(args) == 2 else (np.inf, args[0] if args else None))
+    out = _interpolate_column(np.asarray(col, dtype=np.float64), np.asarray(col.index), max_gap, kind)
+    return col if out is None else pd.Series(out, index=col.index, name=getattr(col, 'name', None))
+
+
+def interpolate_gaps(coords, labels, max_gap, kind):
+    """Every column of coords [F][3 K] through the gap interpolation (triangulation.py:889-894: all columns or, if one of
+    them fails, none -- the caller logs the reference's warning).  Returns the new array."""
+    out = coords.copy()
+    for c in range(coords.shape[1]):
+        col = _interpolate_column(coords[:, c], labels, max_gap, kind)
+        if col is not None:
+            out[:, c] = col
+    return out
+
+
+def fill_gaps(coords, how):
+    """triangulation.py:922-926.  'last_value': every gap takes the last valid value before it, leading gaps the first
+    valid one after them, and what is still missing (a column never seen) or +inf becomes 0; 'zeros': NaN and +inf
+    become 0; anything else leaves the gaps."""
+    if how not in ('last_value', 'zeros'):
+        return coords
+    out = coords.copy()
+    if how == 'last_value':
+        F = out.shape[0]
+        rows = np.arange(F)[:, None]
+        seen = ~np.isnan(out)
+        last = np.maximum.accumulate(np.where(seen, rows, -1), axis=0)                 # row of the last valid sample, or -1
+        nxt = np.minimum.accumulate(np.where(seen, rows, F)[::-1], axis=0)[::-1]       # row of the next valid sample, or F
+        src = np.where(last >= 0, last, np.minimum(nxt, F - 1))
+        filled = np.take_along_axis(out, src, axis=0)
+        out = np.where((last >= 0) | (nxt < F), filled, np.nan)
+    out[np.isnan(out) | (out == np.inf)] = 0
+    return out
+
+
+def gap_spans(x_coords, first, last, max_gap):
+    """triangulation.py:917-919, 946-953: per keypoint, the runs of frames (positions in the trimmed trial) whose X is 0
+    or not finite, as 'a:b' strings -- those short enough to have been interpolated, and the others.  Positions are kept
+    only if they lie strictly between `first` and `last`, the trial's own bounds (the reference compares positions in
+    the trimmed trial with positions in the whole one)."""
+    done, left = [], []
+    for k in range(x_coords.shape[1]):
+        pos = np.flatnonzero((x_coords[:, k] == 0) | ~np.isfinite(x_coords[:, k]))
+        pos = pos[(pos > first) & (pos < last)]
+        runs = np.split(pos, np.flatnonzero(np.diff(pos) > 1) + 1)
+        done.append([f'{r[0]}:{r[-1]}' for r in runs if 0 < len(r) <= max_gap])
+        left.append([f'{r[0]}:{r[-1]}' for r in runs if len(r) > max_gap])
+    return done, left
+
+
+def camera_exclusion_fractions(mask_rows, n_cams):
+    """triangulation.py:933-943: per camera, the share of (frame, keypoint) units that excluded it, from the kernels'
+    excluded-camera bit masks [F'][K]."""
+    flat = mask_rows.reshape(-1).astype(np.uint64)
+    total = flat.size
+    return {c: int(np.count_nonzero((flat >> np.uint64(c)) & np.uint64(1))) / total for c in range(n_cams)}
+
+
+def frame_means(table, skipna=True):
+    """Row means with pandas' DataFrame.mean(axis=1) arithmetic (what the reference trims and reports by)."""
+    import pandas as pd
+    return pd.DataFrame(table).mean(axis=1, skipna=skipna).to_numpy()
+
+
+def column_means(table):
+    """Column means with pandas' DataFrame.mean() arithmetic (NaN skipped)."""
+    import pandas as pd
+    return pd.DataFrame(table).mean().to_numpy()
 
 
 # triangulation.py:93-148

@@ -1,9 +1,9 @@
 """.trc writer / reader, byte-compatible with the reference.
 
-make_trc restates triangulation.py:151-215 (header lines :195-199, Z-up -> Y-up column
-permutation of common.py:596-612, rows through ``DataFrame.to_csv(sep='\\t', header=None,
-lineterminator='\\n')`` so that float formatting -- shortest repr, NaN as empty field -- is the
-reference's own).  read_trc restates common.py:149-175.
+write_trc / make_trc produce the file of triangulation.py:151-215: the five header lines (:195-199, here a table of
+labels and facts), the Z-up -> Y-up column order of common.py:596-612, and the rows of ``DataFrame.to_csv(sep='\\t',
+header=None, lineterminator='\\n')`` -- shortest-repr floats, NaN as an empty field -- from the native formatter.
+load_trc / read_trc read such a file back (the reader contract of common.py:149-175).
 """
 import glob
 import logging
@@ -13,11 +13,10 @@ import numpy as np
 import pandas as pd
 
 
-def zup2yup(Q):
-    """common.py:596-612: (X, Y, Z) -> (Y, Z, X) per marker, on a DataFrame with 3N columns."""
-    cols = list(Q.columns)
-    cols = np.array([[cols[i * 3 + 1], cols[i * 3 + 2], cols[i * 3]] for i in range(int(len(cols) / 3))]).flatten()
-    return Q[cols]
+def yup_columns(n_markers):
+    """Column order of a .trc row for data held (X, Y, Z) in the Z-up frame: the reference's zup2yup (common.py:596-612)
+    writes (Y, Z, X) of every marker."""
+    return (3 * np.arange(n_markers)[:, None] + np.array([1, 2, 0])[None, :]).ravel()
 
 
 def mp4_frame_rate(path):
@@ -70,37 +69,48 @@ def resolve_frame_rate(config_dict):
     return frame_rate
 
 
-def make_trc(config_dict, Q, keypoints_names, id_person=-1):
-    """triangulation.py:151-215.  Q: DataFrame, 3 columns (X, Y, Z in the Z-up frame) per keypoint,
-    index = absolute frame numbers.  Returns the path written."""
-    project_dir = config_dict.get('project').get('project_dir')
-    multi_person = config_dict.get('project').get('multi_person')
-    base = os.path.basename(os.path.realpath(project_dir))
-    seq_name = f'{base}_P{id_person}' if multi_person else f'{base}'
-    pose3d_dir = os.path.join(project_dir, 'pose-3d')
-    frame_rate = resolve_frame_rate(config_dict)
+# The five header lines of a .trc file (triangulation.py:195-199), as a table: the labels of line 2 and how the values of
+# line 3 are made from the run's facts.
+_HEADER_FIELDS = (('DataRate', 'rate'), ('CameraRate', 'rate'), ('NumFrames', 'n_frames'), ('NumMarkers', 'n_markers'),
+                  ('Units', 'units'), ('OrigDataRate', 'rate'), ('OrigDataStartFrame', 'first_frame'), ('OrigNumFrames', 'n_frames'))
 
-    trc_f = f'{seq_name}_{Q.index[0]}-{Q.index[-1]}.trc'
-    DataRate = CameraRate = OrigDataRate = frame_rate
-    NumFrames = len(Q)
-    NumMarkers = len(keypoints_names)
-    header_trc = ['PathFileType\t4\t(X/Y/Z)\t' + trc_f,
-                  'DataRate\tCameraRate\tNumFrames\tNumMarkers\tUnits\tOrigDataRate\tOrigDataStartFrame\tOrigNumFrames',
-                  '\t'.join(map(str, [DataRate, CameraRate, NumFrames, NumMarkers, 'm', OrigDataRate, Q.index[0], NumFrames])),
-                  'Frame#\tTime\t' + '\t\t\t'.join(keypoints_names) + '\t\t\t',
-                  '\t\t' + '\t'.join([f'X{i + 1}\tY{i + 1}\tZ{i + 1}' for i in range(len(keypoints_names))]) + '\t']
-    Q = zup2yup(Q)
-    Q.insert(0, 't', Q.index / frame_rate)
+
+def header_lines(file_name, marker_names, frame_rate, first_frame, n_frames):
+    facts = {'rate': frame_rate, 'n_frames': n_frames, 'n_markers': len(marker_names), 'units': 'm', 'first_frame': first_frame}
+    axes = [f'{axis}{i}' for i in range(1, len(marker_names) + 1) for axis in 'XYZ']
+    return ['\t'.join(('PathFileType', '4', '(X/Y/Z)', file_name)),
+            '\t'.join(label for label, _ in _HEADER_FIELDS),
+            '\t'.join(str(facts[key]) for _, key in _HEADER_FIELDS),
+            'Frame#\tTime\t' + ''.join(name + '\t\t\t' for name in marker_names),
+            '\t\t' + ''.join(axis + '\t' for axis in axes)]
+
+
+def write_trc(pose3d_dir, seq_name, frames, coords_zup, marker_names, frame_rate):
+    """One .trc file `<seq_name>_<first>-<last>.trc` from frames [F] (absolute numbers) and coords_zup [F][3 K] (X, Y, Z
+    per marker, Z up): the file make_trc (triangulation.py:151-215) writes.  Returns its real path."""
+    frames = np.asarray(frames)
+    coords_zup = np.asarray(coords_zup, dtype=np.float64)
+    file_name = f'{seq_name}_{frames[0]}-{frames[-1]}.trc'
     if not os.path.exists(pose3d_dir):
         os.mkdir(pose3d_dir)
-    trc_path = os.path.realpath(os.path.join(pose3d_dir, trc_f))
-    with open(trc_path, 'w') as trc_o:
-        for line in header_trc:
-            trc_o.write(line + '\n')
-    # the data rows: DataFrame.to_csv(sep='\t', index=True, header=None, lineterminator='\n') of the reference
-    # (:214), written by the native formatter (csrc/p2s_trc.cpp: repr() floats, NaN -> empty field)
-    write_rows(trc_path, np.asarray(Q.index), Q.iloc[:, 0].to_numpy(), Q.iloc[:, 1:].to_numpy())
+    trc_path = os.path.realpath(os.path.join(pose3d_dir, file_name))
+    with open(trc_path, 'w') as fh:
+        fh.write('\n'.join(header_lines(file_name, marker_names, frame_rate, frames[0], len(frames))) + '\n')
+    # rows `frame <tab> frame / rate <tab> coordinates`, floats as repr() and NaN as an empty field (what DataFrame.to_csv
+    # gives the reference), by the native formatter csrc/p2s_trc.cpp
+    write_rows(trc_path, frames, frames / frame_rate, coords_zup[:, yup_columns(len(marker_names))])
     return trc_path
+
+
+def make_trc(config_dict, Q, keypoints_names, id_person=-1):
+    """The reference's entry (triangulation.py:151-215): Q is a DataFrame of 3 columns (X, Y, Z, Z up) per keypoint
+    indexed by absolute frame number.  Returns the path written."""
+    project_dir = config_dict.get('project').get('project_dir')
+    seq_name = os.path.basename(os.path.realpath(project_dir))
+    if config_dict.get('project').get('multi_person'):
+        seq_name += f'_P{id_person}'
+    return write_trc(os.path.join(project_dir, 'pose-3d'), seq_name, np.asarray(Q.index), Q.to_numpy(dtype=np.float64), keypoints_names,
+                     resolve_frame_rate(config_dict))
 
 
 def write_rows(trc_path, frames, time_col, data):
@@ -120,18 +130,27 @@ def write_rows(trc_path, frames, time_col, data):
     _lib.check(lib.p2s_trc_append_rows(os.fsencode(trc_path), n_rows, data.shape[1], ptr(frames), ptr(time_col), ptr(data), 0))
 
 
+def load_trc(trc_path):
+    """-> (frames int64 [F], time [F], coords [F][3 K] as stored (Y-up), marker names, the 5 header lines).  The number
+    block goes through pandas' C tokenizer, the parser the reference reads it with (common.py:163), so that a value
+    written back is the digit string it was read from."""
+    with open(trc_path, 'r') as fh:
+        header = [next(fh) for _ in range(5)]
+    markers = [m.strip() for m in header[3].split('\t')[2::3] if m.strip()]
+    block = pd.read_csv(trc_path, sep='\t', skiprows=5, header=None, encoding='utf-8')
+    n_coord = 3 * len(markers)
+    coords = block.iloc[:, 2:2 + n_coord].to_numpy(dtype=np.float64)
+    if coords.shape[1] != n_coord:
+        raise ValueError(f'{n_coord} coordinate columns expected for {len(markers)} markers, found {coords.shape[1]}')
+    return block.iloc[:, 0].to_numpy(), block.iloc[:, 1].to_numpy(dtype=np.float64), coords, markers, header
+
+
 def read_trc(trc_path):
-    """common.py:149-175 -> (Q_coords, frames_col, time_col, markers, header)."""
+    """The reference's reader contract (common.py:149-175) -> (Q_coords, frames_col, time_col, markers, header): a
+    DataFrame with every marker's name on its three columns, two Series, the marker names, the header lines."""
     try:
-        with open(trc_path, 'r') as trc_file:
-            header = [next(trc_file) for _ in range(5)]
-        markers = header[3].split('\t')[2::3]
-        markers = [m.strip() for m in markers if m.strip()]
-        trc_df = pd.read_csv(trc_path, sep='\t', skiprows=4, encoding='utf-8')
-        frames_col, time_col = trc_df.iloc[:, 0], trc_df.iloc[:, 1]
-        Q_coords = trc_df.drop(trc_df.columns[[0, 1]], axis=1)
-        Q_coords = Q_coords.loc[:, ~Q_coords.columns.str.startswith('Unnamed')]
-        Q_coords.columns = np.array([[m, m, m] for m in markers]).ravel().tolist()
-        return Q_coords, frames_col, time_col, markers, header
+        frames, time_col, coords, markers, header = load_trc(trc_path)
+        Q_coords = pd.DataFrame(coords, columns=[m for m in markers for _ in range(3)])
+        return Q_coords, pd.Series(frames), pd.Series(time_col), markers, header
     except Exception as e:
         raise ValueError(f'Error reading TRC file at {trc_path}: {e}')

@@ -11,7 +11,6 @@ import logging
 import os
 
 import numpy as np
-import pandas as pd
 
 from . import calib as calib_mod
 from . import poseio, postproc, skeletons, trc
@@ -96,15 +95,60 @@ def track_persons(Q, err, nex, ids_mask, f_range, multi_person, max_distance_m, 
     return Q_out, e_out, n_out, m_out
 
 
-def _cam_exclusion_fractions(mask_rows, n_cams, K):
-    """triangulation.py:933-943 from the excluded-camera bit masks of the kept frames."""
-    frame_count = mask_rows.shape[0]
-    total = frame_count * K
-    counts = {}
-    flat = mask_rows.reshape(-1).astype(np.uint64)
-    for c in range(n_cams):
-        counts[c] = int(np.count_nonzero((flat >> np.uint64(c)) & np.uint64(1))) / total
-    return counts
+class PersonTrial:
+    """What the stage keeps of one person after the frame-sequential steps: the kept section [start, end) of the trial
+    (positions in f_range), the file written, and the figures the report prints."""
+
+    def __init__(self, start, end):
+        self.start, self.end = start, end
+        self.kept = False
+        self.trc_path = ''
+        self.err_per_kpt = self.excl_per_kpt = None            # [K] means over the kept frames
+        self.err_mean = self.excl_mean = None                  # means over the kept frames of the per-frame means
+        self.cam_fractions = {}
+        self.interpolated, self.not_interpolated = [], []
+
+
+def finish_person(n, coords, err, n_excl, masks, frames, settings, config_dict, keypoints_names, n_cams, write):
+    """triangulation.py:888-953 for one person, on arrays: coords [F][3 K], err / n_excl [F][K] float, masks [F][K] u32,
+    frames [F] absolute frame numbers.  Interpolates the short gaps, keeps the section(s) of frames with a mean error,
+    fills the long gaps, writes the .trc file (rank 0) and collects the report's figures."""
+    K = len(keypoints_names)
+    if settings['interpolation'] != 'none':
+        try:
+            coords = postproc.interpolate_gaps(coords, frames, settings['max_gap'], settings['interpolation'])
+        except Exception:
+            logging.warning(f'Interpolation was not possible for person {n}. This means that not enough points are available, which is often due to a bad calibration.')
+    err_frame = postproc.frame_means(err, skipna=not settings['remove_incomplete_frames'])       # :897
+    excl_frame = postproc.frame_means(n_excl)
+    start, end = postproc.indices_of_first_last_non_nan_chunks(err_frame, min_chunk_size=settings['min_chunk_size'],
+                                                               chunk_choice_method=settings['sections_to_keep'])
+    person = PersonTrial(start, end)
+    if end - start <= settings['min_chunk_size']:                                                # :903-910
+        logging.info(f'\nPerson {n}: Less than {settings["min_chunk_size"]} valid frames in a row. Deleting person.')
+        return person
+    person.kept = True
+    coords = coords[start:end]
+    done, left = postproc.gap_spans(coords[:, ::3], start, end, settings['max_gap'])             # before the long gaps are filled
+    coords = postproc.fill_gaps(coords, settings['fill_large_gaps_with'])
+    if write:
+        seq_name = os.path.basename(os.path.realpath(config_dict.get('project').get('project_dir')))
+        if config_dict.get('project').get('multi_person'):
+            seq_name += f'_P{n}'
+        person.trc_path = trc.write_trc(os.path.join(config_dict.get('project').get('project_dir'), 'pose-3d'), seq_name,
+                                        frames[start:end], coords, keypoints_names, trc.resolve_frame_rate(config_dict))
+        if settings['make_c3d']:
+            logging.warning('make_c3d: the c3d package is not available in this build; only the .trc file was written.')
+    person.err_per_kpt = postproc.column_means(err[start:end])
+    person.excl_per_kpt = postproc.column_means(n_excl[start:end])
+    person.err_mean = postproc.column_means(err_frame[start:end, None])[0]
+    person.excl_mean = postproc.column_means(excl_frame[start:end, None])[0]
+    person.cam_fractions = postproc.camera_exclusion_fractions(masks[start:end], n_cams)
+    if settings['show_interp_indices']:
+        person.interpolated, person.not_interpolated = done, left
+    else:
+        person.interpolated, person.not_interpolated = None, []
+    return person
 
 
 def triangulate_all(config_dict):
@@ -193,73 +237,18 @@ def triangulate_all(config_dict):
     Qk, ek, nk, mk = gathered
 
     Q_rows, e_rows, n_rows, m_rows = track_persons(Qk, ek, nk, mk, f_range, multi_person, max_distance_m, n_cams)
-    index = range(*f_range)
-    Q_tot = [pd.DataFrame(Q_rows[:, n].reshape(len(index), keypoints_nb * 3), index=index) for n in range(nb_persons)]
-    error_tot = [pd.DataFrame(e_rows[:, n].astype(np.float64), index=index) for n in range(nb_persons)]
-    nb_cams_excluded_tot = [pd.DataFrame(n_rows[:, n].astype(np.float64), index=index) for n in range(nb_persons)]
-
-    cam_excluded_count, interp_frames, non_interp_frames, f_range_trimmed, trc_paths = [], [], [], [], []
-    for n in range(nb_persons):
-        if interpolation_kind != 'none':                                      # :889-894
-            try:
-                Q_tot[n] = Q_tot[n].apply(postproc.interpolate_zeros_nans, axis=0, args=[interp_gap_smaller_than, interpolation_kind])
-            except Exception:
-                logging.warning(f'Interpolation was not possible for person {n}. This means that not enough points are available, which is often due to a bad calibration.')
-
-        error_tot[n]['mean'] = error_tot[n].mean(axis=1, skipna=not remove_incomplete_frames)   # :897
-        nb_cams_excluded_tot[n]['mean'] = nb_cams_excluded_tot[n].mean(axis=1)
-        start, end = postproc.indices_of_first_last_non_nan_chunks(error_tot[n]['mean'], min_chunk_size=min_chunk_size,
-                                                                   chunk_choice_method=sections_to_keep)
-        f_range_trimmed.append([start, end])
-
-        if end - start <= min_chunk_size:                                     # :903-910
-            nb_cams_excluded_tot[n] = pd.DataFrame(columns=nb_cams_excluded_tot[n].columns)
-            cam_excluded_count.append({})
-            interp_frames.append([])
-            non_interp_frames.append([])
-            trc_paths.append('')
-            logging.info(f'\nPerson {n}: Less than {min_chunk_size} valid frames in a row. Deleting person.')
-            continue
-
-        Q_tot[n] = Q_tot[n].iloc[start:end]                                  # :913-916
-        error_tot[n] = error_tot[n].iloc[start:end]
-        nb_cams_excluded_tot[n] = nb_cams_excluded_tot[n].iloc[start:end]
-        masks_kept = m_rows[start:end, n]
-        zero_nan_frames = np.where(Q_tot[n].iloc[:, ::3].T.eq(0) | ~np.isfinite(Q_tot[n].iloc[:, ::3].T))
-        zero_nan_frames_per_kpt = [zero_nan_frames[1][np.where(zero_nan_frames[0] == k)[0]] for k in range(keypoints_nb)]
-        zero_nan_frames_per_kpt = [z[(start < z) & (end > z)] for z in zero_nan_frames_per_kpt]
-
-        if fill_large_gaps_with == 'last_value':                              # :922-926
-            Q_tot[n] = Q_tot[n].ffill(axis=0).bfill(axis=0)
-            Q_tot[n] = Q_tot[n].replace([np.nan, np.inf], 0)
-        elif fill_large_gaps_with == 'zeros':
-            Q_tot[n] = Q_tot[n].replace([np.nan, np.inf], 0)
-
-        if rank == 0:
-            trc_paths.append(trc.make_trc(config_dict, Q_tot[n], keypoints_names, id_person=n))   # :929
-            if make_c3d:
-                logging.warning('make_c3d: the c3d package is not available in this build; only the .trc file was written.')
-        else:
-            trc_paths.append('')
-
-        cam_excluded_count.append(_cam_exclusion_fractions(masks_kept, n_cams, keypoints_nb))   # :933-943
-
-        if show_interp_indices:                                               # :946-953
-            gaps = [np.where(np.diff(zero_nan_frames_per_kpt[k]) > 1)[0] + 1 for k in range(keypoints_nb)]
-            sequences = [np.split(zero_nan_frames_per_kpt[k], gaps[k]) for k in range(keypoints_nb)]
-            interp_frames.append([[f'{seq[0]}:{seq[-1]}' for seq in seq_kpt if len(seq) <= interp_gap_smaller_than and len(seq) > 0] for seq_kpt in sequences])
-            non_interp_frames.append([[f'{seq[0]}:{seq[-1]}' for seq in seq_kpt if len(seq) > interp_gap_smaller_than] for seq_kpt in sequences])
-        else:
-            interp_frames.append(None)
-            non_interp_frames.append([])
-
-    if np.all(np.diff(np.array(f_range_trimmed)) == 0):                       # :955-956
+    frames = np.arange(*f_range)
+    settings = {'interpolation': interpolation_kind, 'max_gap': interp_gap_smaller_than, 'remove_incomplete_frames': remove_incomplete_frames,
+                'sections_to_keep': sections_to_keep, 'min_chunk_size': min_chunk_size, 'fill_large_gaps_with': fill_large_gaps_with,
+                'show_interp_indices': show_interp_indices, 'make_c3d': make_c3d}
+    persons = [finish_person(n, Q_rows[:, n].reshape(len(frames), keypoints_nb * 3), e_rows[:, n].astype(np.float64),
+                             n_rows[:, n].astype(np.float64), m_rows[:, n], frames, settings, config_dict, keypoints_names, n_cams,
+                             write=(rank == 0)) for n in range(nb_persons)]
+    if all(p.end == p.start for p in persons):                                 # :955-956
         raise Exception('No persons have been triangulated. Please check your calibration and your synchronization, or the triangulation parameters in Config.toml.')
-
     if rank == 0:
-        recap_triangulate(config_dict, error_tot, nb_cams_excluded_tot, keypoints_names, cam_excluded_count,
-                          interp_frames, non_interp_frames, f_range_trimmed, f_range, trc_paths, calib_file)
-    return trc_paths
+        recap_triangulate(config_dict, persons, keypoints_names, f_range, calib_file)
+    return [p.trc_path for p in persons]
 
 
 # ---- the stage's report (triangulation.py:255-360): message templates as data, one pass over a table of values -------
@@ -304,8 +293,7 @@ def _camera_sentence(fractions):
     return ''.join(parts)
 
 
-def recap_triangulate(config_dict, error, nb_cams_excluded, keypoints_names, cam_excluded_count, interp_frames,
-                      non_interp_frames, f_range_trimmed, f_range, trc_paths, calib_file):
+def recap_triangulate(config_dict, persons, keypoints_names, f_range, calib_file):
     """The report of triangulation.py:255-360: per keypoint the mean reprojection error (px, and metres through the first
     camera's focal length and distance) and mean number of excluded cameras, the interpolated frame spans, the
     trial-wide means, the thresholds in force, each camera's share of exclusions, where the file went."""
@@ -316,42 +304,41 @@ def recap_triangulate(config_dict, error, nb_cams_excluded, keypoints_names, cam
     first_cam = calib[cal_keys[0]]
     px_to_m = float(np.sqrt(np.sum(np.array(first_cam['translation'], dtype=np.float64) ** 2))) / first_cam['matrix'][0][0]
     kind = tcfg.get('interpolation')
-    min_chunk = tcfg.get('min_chunk_size', 10)
     say = logging.info
 
     say('')
-    persons = [n for n in range(len(error)) if f_range_trimmed[n][1] - f_range_trimmed[n][0] > min_chunk]
-    for n in persons:
-        first, last = f_range_trimmed[n]
-        if len(error) > 1:
+    for n, person in enumerate(persons):
+        if not person.kept:
+            continue
+        if len(persons) > 1:
             say(_MSG['participant'].format(n=n))
         for idx, name in enumerate(keypoints_names):
-            px = np.around(error[n].iloc[:, idx].mean(), decimals=1)
+            px = np.around(person.err_per_kpt[idx], decimals=1)
             say(_MSG['keypoint'].format(name=name, px=px, m=np.around(px * px_to_m, decimals=3),
-                                        cams=np.around(nb_cams_excluded[n].iloc[:, idx].mean(), decimals=2)))
+                                        cams=np.around(person.excl_per_kpt[idx], decimals=2)))
             if not tcfg.get('show_interp_indices'):
                 continue
             if kind == 'none':
                 say(_MSG['interp_off'])
                 continue
-            done, left = list(interp_frames[n][idx]), list(non_interp_frames[n][idx])
+            done, left = list(person.interpolated[idx]), list(person.not_interpolated[idx])
             if not done and not left:
                 say(_MSG['none_needed'])
             if done:
                 say(_MSG['interpolated'].format(spans=_spans(done)))
             if left:
                 say(_MSG['not_interpolated'].format(spans=_spans(left)))
-        px = np.around(error[n]['mean'].mean(), decimals=1)
-        say(_MSG['overall'].format(first=first, last=last, px=px, mm=np.around(px * px_to_m * 1000, decimals=1)))
+        px = np.around(person.err_mean, decimals=1)
+        say(_MSG['overall'].format(first=person.start, last=person.end, px=px, mm=np.around(px * px_to_m * 1000, decimals=1)))
         say(_MSG['thresholds'].format(lik=tcfg.get('likelihood_threshold_triangulation'), thr=tcfg.get('reproj_error_threshold_triangulation')))
         if kind != 'none':
             say(_MSG['gaps'].format(kind=kind, gap=tcfg.get('interp_if_gap_smaller_than'),
                                     filler=_FILLERS.get(tcfg.get('fill_large_gaps_with'), 'NaNs')))
-        say(_MSG['excluded'].format(cams=np.around(nb_cams_excluded[n]['mean'].mean(), decimals=2)))
-        if len(range(first, last)) < len(range(*f_range)):
-            logging.warning(_MSG['trimmed'].format(span=f_range_trimmed[n]))
-        say(_camera_sentence({cam_names[i]: v for i, v in cam_excluded_count[n].items()}))
-        say(_MSG['stored'].format(path=trc_paths[n]))
+        say(_MSG['excluded'].format(cams=np.around(person.excl_mean, decimals=2)))
+        if len(range(person.start, person.end)) < len(range(*f_range)):
+            logging.warning(_MSG['trimmed'].format(span=[person.start, person.end]))
+        say(_camera_sentence({cam_names[i]: v for i, v in person.cam_fractions.items()}))
+        say(_MSG['stored'].format(path=person.trc_path))
 
     say('\n\n')
     if tcfg.get('make_c3d'):
