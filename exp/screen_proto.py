@@ -168,3 +168,45 @@ for c in (0.5, 1.0, 2.0, 4.0):
     surv = fin & (e_lo <= thr) & (e_lo <= e_hi.min(1)[:, None])
     print(f'model c={c}: guarded {gg.sum() / fin.sum():.4f}; max diff/m {ratio.max():.3f}; survivors/unit {surv.sum() / H:.3f}; '
           f'wrongly pruned {np.sum((best <= thr) & ~surv[np.arange(H), e64.argmin(1)])}')
+
+# ---- variant: one solve fewer.  q from lam1 (= n_iter 1), dlam measured by one more Rayleigh quotient at that q ----------
+if len(sys.argv) > 6 and sys.argv[6] == 'short':
+    with np.errstate(all='ignore'):
+        e32s = np.full((H, S), np.inf, dtype=f32); dls = np.zeros((H, S), dtype=f32); conds = np.zeros((H, S), dtype=f32)
+        for si, sub in enumerate(subsets):
+            keep = vh.copy(); keep[:, list(sub)] = False
+            ok = vh[:, list(sub)].all(1) & (keep.sum(1) >= 2)
+            Mj, gj, hj = M32.copy(), g32.copy(), h32.copy()
+            for j in sub:
+                a, b = Ar[:, j, :3], Br[:, j, :3]
+                Mj = Mj - w2[:, j, None, None] * (a[:, :, None] * a[:, None, :] + b[:, :, None] * b[:, None, :])
+                gj = gj - w2[:, j, None] * (a * u0[:, j, None] + b * v0[:, j, None])
+                hj = hj - w2[:, j] * (u0[:, j] * u0[:, j] + v0[:, j] * v0[:, j])
+            def ray(q):
+                Mq = np.einsum('uij,uj->ui', Mj, q)
+                num = (Mq * q).sum(-1) + f32(2) * (gj * q).sum(-1) + hj
+                Qn = Q032 + q
+                return (num / ((Qn * Qn).sum(-1) + f32(1))).astype(f32)
+            q, cd = inv3_apply(Mj, -gj)
+            lam1 = ray(q)
+            q, cd = inv3_apply(Mj - lam1[:, None, None] * eye, lam1[:, None] * Q032 - gj)
+            lam2 = ray(q)
+            conds[:, si] = cd
+            dls[:, si] = np.abs(lam2 - lam1) / np.maximum(np.abs(lam2), f32(1e-30))
+            Qn = np.concatenate([Q032 + q, np.ones((H, 1), dtype=f32)], -1)
+            pr = np.einsum('cij,uj->uci', P32, Qn).astype(f32)
+            uu = pr[..., 0] - x32 * pr[..., 2]; vv = pr[..., 1] - y32 * pr[..., 2]
+            d = np.sqrt(uu * uu + vv * vv) / np.abs(pr[..., 2])
+            e = (d * keep).sum(-1) / keep.sum(-1).astype(f32)
+            e32s[:, si] = np.where(ok, e, np.inf)
+        diffs = np.abs(e32s.astype(np.float64) - e64)
+    diffs = np.where(fin, np.nan_to_num(diffs, nan=np.inf), 0.0)
+    gg = fin & (conds >= 3e-3) & np.isfinite(e32s) & (dls <= 0.25)
+    print(f'SHORT variant: |e32 - e64| max {diffs[fin].max():.3e}, p99.9 {np.quantile(diffs[fin], 0.999):.3e}')
+    for c in (1.0, 2.0, 4.0, 8.0):
+        m = 0.02 + e32s * (1e-3 + c * dls)
+        ratio = np.where(gg, diffs / m, 0.0)
+        e_lo = np.where(gg, e32s - m, -np.inf); e_hi = np.where(gg, e32s + m, np.inf)
+        surv = fin & (e_lo <= thr) & (e_lo <= e_hi.min(1)[:, None])
+        print(f'  short c={c}: guarded {gg.sum() / fin.sum():.4f}; max diff/m {ratio.max():.3f}; survivors/unit {surv.sum() / H:.3f}; '
+              f'wrongly pruned {np.sum((best <= thr) & ~surv[np.arange(H), e64.argmin(1)])}')

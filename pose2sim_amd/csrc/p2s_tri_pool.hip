@@ -82,6 +82,27 @@ __device__ __forceinline__ void load_obs(const P2sTriArgs &a, int C, uint32_t b,
     }
 }
 
+// Cameras c0 .. c0 + 7 of one unit (the 9-16 camera kernels work on the observations eight cameras at a time: 48 registers
+// of observations beside the eigen-solve spilled ~400 B per lane in round 2).
+template <typename T, bool EXACT, bool WITH_W = true>
+__device__ __forceinline__ void load_half(const P2sTriArgs &a, int C, uint32_t b, uint32_t k, int c0, RegObs<T, 8> &obs) {
+    const unsigned char *chunk = reinterpret_cast<const unsigned char *>(a.xyl) +
+                                 (size_t)a.block0 * (size_t)C * (size_t)a.K * 3u * sizeof(T);
+    const uint32_t voff = (b * (uint32_t)(C * a.K) + k) * (uint32_t)(3 * sizeof(T));
+    const uint32_t cam_stride = (uint32_t)a.K * (uint32_t)(3 * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (EXACT || c0 + i < C) {
+            const T *p = reinterpret_cast<const T *>(chunk + (size_t)(c0 + i) * cam_stride + voff);
+            obs.x[i] = __builtin_nontemporal_load(p);
+            obs.y[i] = __builtin_nontemporal_load(p + 1);
+            obs.w[i] = WITH_W ? __builtin_nontemporal_load(p + 2) : (T)0;
+        } else {
+            obs.x[i] = obs.y[i] = obs.w[i] = (T)0;
+        }
+    }
+}
+
 __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -505,6 +526,40 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         n_used = 0; n_over = 0;
     };
 
+    // ---- a tile's results leave at once, 16-byte stores of contiguous memory; the searching units' results are patched
+    // over them after the search
+    auto store_tile = [&](const uint32_t tile) {
+        {
+            const int64_t wave_u0 = (int64_t)tile << 6;
+            const int64_t gu0 = a.block0 * K + wave_u0;
+            const int64_t n_left = n_units - wave_u0;
+            double *Qw = a.Q + gu0 * 3;
+            float *Ew = a.err + gu0;
+            uint32_t *Mw = a.mask + gu0;
+            uint8_t *Xw = a.n_excl + gu0;
+            const bool al16 = ((reinterpret_cast<uintptr_t>(Qw) | reinterpret_cast<uintptr_t>(Ew) |
+                                reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(Xw)) & 15) == 0;
+            if (n_left >= 64 && al16) {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v2d *src = reinterpret_cast<const v2d *>(sQ);
+                v2d *dst = reinterpret_cast<v2d *>(Qw);
+                dst[lane] = src[lane];
+                if (lane < 32) dst[64 + lane] = src[64 + lane];
+                else if (lane < 48) reinterpret_cast<v4u *>(Ew)[lane - 32] = reinterpret_cast<const v4u *>(sE)[lane - 32];
+                else if (lane < 52) reinterpret_cast<v4u *>(Xw)[lane - 48] = reinterpret_cast<const v4u *>(sX)[lane - 48];
+                if (lane < 16) reinterpret_cast<v4u *>(Mw)[lane] = reinterpret_cast<const v4u *>(sM)[lane];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int idx = r * 64 + lane;
+                    if (idx < 3 * n_left) Qw[idx] = sQ[idx];
+                }
+                if (lane < n_left) { Ew[lane] = __uint_as_float(sE[lane]); Mw[lane] = sM[lane]; Xw[lane] = sX[lane]; }
+            }
+        }
+    };
+
     // ---- level 0 of the wave's tiles (triangulation.py:404-505 with nb_cams_off = 0), one after the other ---------------
     // `prefetch` is called once the eigen-solve is through (the point of highest register pressure): a tile requests the
     // next tile's observations there, so that they travel during its reprojection pass instead of after it.
@@ -546,44 +601,139 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             n_over = max(0, tot - NSLOT);
             n_used = min(NSLOT, tot);
         }
-        // ---- the tile's results leave at once, 16-byte stores of contiguous memory; the searching units' results are
-        // patched over them after the search
         wsync();
-        {
-            const int64_t wave_u0 = (int64_t)tile << 6;
-            const int64_t gu0 = a.block0 * K + wave_u0;
-            const int64_t n_left = n_units - wave_u0;
-            double *Qw = a.Q + gu0 * 3;
-            float *Ew = a.err + gu0;
-            uint32_t *Mw = a.mask + gu0;
-            uint8_t *Xw = a.n_excl + gu0;
-            const bool al16 = ((reinterpret_cast<uintptr_t>(Qw) | reinterpret_cast<uintptr_t>(Ew) |
-                                reinterpret_cast<uintptr_t>(Mw) | reinterpret_cast<uintptr_t>(Xw)) & 15) == 0;
-            if (n_left >= 64 && al16) {
-                typedef double v2d __attribute__((ext_vector_type(2)));
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v2d *src = reinterpret_cast<const v2d *>(sQ);
-                v2d *dst = reinterpret_cast<v2d *>(Qw);
-                dst[lane] = src[lane];
-                if (lane < 32) dst[64 + lane] = src[64 + lane];
-                else if (lane < 48) reinterpret_cast<v4u *>(Ew)[lane - 32] = reinterpret_cast<const v4u *>(sE)[lane - 32];
-                else if (lane < 52) reinterpret_cast<v4u *>(Xw)[lane - 48] = reinterpret_cast<const v4u *>(sX)[lane - 48];
-                if (lane < 16) reinterpret_cast<v4u *>(Mw)[lane] = reinterpret_cast<const v4u *>(sM)[lane];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int idx = r * 64 + lane;
-                    if (idx < 3 * n_left) Qw[idx] = sQ[idx];
-                }
-                if (lane < n_left) { Ew[lane] = __uint_as_float(sE[lane]); Mw[lane] = sM[lane]; Xw[lane] = sX[lane]; }
-            }
-        }
+        store_tile(tile);
     };
+    // 9-16 cameras: the same steps with the observations taken eight cameras at a time -- read for the normal matrix, read
+    // again (from L2) for the reprojection error, and a third time by the few lanes that park their unit in a slot -- so
+    // that no more than 48 registers of observations are ever live, and none during the eigen-solve.
+    auto level0_wide = [&](const int t) {
+        const uint32_t tile = tile0 + (uint32_t)t * tstride;
+        bool act;
+        const uint32_t u = unit_of(tile, act);
+        const uint32_t ub = u / (uint32_t)K, uk = u % (uint32_t)K;
+        RegObs<T, 8> h0, h1;
+        h0.lik_thr = a.lik_thr; h1.lik_thr = a.lik_thr;
+        load_half<T, EXACT>(a, C, ub, uk, 0, h0);
+        load_half<T, EXACT>(a, C, ub, uk, 8, h1);
+        double N[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) N[i] = 0.0;
+        uint32_t nanmask = 0, zeromask = 0;
+        auto accumulate = [&](const int c0, const RegObs<T, 8> &h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (EXACT || c0 + i < C) {
+                    const T x = h.x[i], y = h.y[i], w = h.w[i];
+                    const bool isn = !(w == w) || ((double)w < a.lik_thr);
+                    const bool isz = (w == (T)0) && !isn;
+                    nanmask |= isn ? (1u << (c0 + i)) : 0u;
+                    zeromask |= isz ? (1u << (c0 + i)) : 0u;
+                    const bool ok = !(isn || isz);
+                    accum_camera<1>(N, cams[c0 + i].P, (double)(ok ? x : (T)0), (double)(ok ? y : (T)0), (double)(ok ? w : (T)0));
+                }
+            }
+        };
+        accumulate(0, h0);
+        accumulate(8, h1);
+        const uint32_t dmask = nanmask | zeromask;
+        const uint32_t valid = allmask & ~dmask;
+        const int V = __popc(dmask);
+        const int Lmax = act ? C - a.min_cams - V : -1;
+        double q[3];
+        smallest_eigvec(N, q);
+        uint32_t ub2 = ub;
+        asm volatile("" : "+v"(ub2) : "v"(q[0]));                          // the second read not before the eigen-solve
+        load_half<T, EXACT, false>(a, C, ub2, uk, 0, h0);                  // x and y only
+        if (C - V < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
+        double sum = 0.0;
+        bool irregular = false;
+        auto distances = [&](const int c0, const RegObs<T, 8> &h) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (EXACT || c0 + i < C) {
+                    const bool kk = (valid >> (c0 + i)) & 1u;
+                    bool reg;
+                    const double d = camera_distance<false>(cams + (c0 + i), q, (double)h.x[i], (double)h.y[i], reg);
+                    irregular = irregular || (kk && !reg);
+                    sum += kk ? d : 0.0;
+                }
+            }
+        };
+        distances(0, h0);
+        asm volatile("" : "+v"(ub2));                                      // (addresses are recomputed, not kept: 2 registers per camera)
+        load_half<T, EXACT, false>(a, C, ub2, uk, 8, h0);
+        distances(8, h0);
+        if (__any(irregular)) {                                            // rare: some wanted camera is degenerate / NaN
+            double sum2 = 0.0;
+            auto exact = [&](const int c0, const RegObs<T, 8> &h) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (EXACT || c0 + i < C) {
+                        const double d = camera_distance_exact(cams + (c0 + i), q[0], q[1], q[2], (double)h.x[i], (double)h.y[i]);
+                        sum2 += ((valid >> (c0 + i)) & 1u) ? d : 0.0;
+                    }
+                }
+            };
+            load_half<T, EXACT, false>(a, C, ub2, uk, 0, h0);
+            exact(0, h0);
+            load_half<T, EXACT, false>(a, C, ub2, uk, 8, h0);
+            exact(8, h0);
+            sum = irregular ? sum2 : sum;
+        }
+        const double e = sum * fast_rcp((double)__popc(valid));
+        const bool ran = Lmax >= 0;
+        const bool ok = ran && (e <= thr);
+        if (t > 0) wsync();
+        sQ[lane * 3 + 0] = ok ? q[0] : d_nan();
+        sQ[lane * 3 + 1] = ok ? q[1] : d_nan();
+        sQ[lane * 3 + 2] = ok ? q[2] : d_nan();
+        sE[lane] = __float_as_uint(ok ? (float)e : __builtin_nanf(""));
+        sM[lane] = ran ? nanmask : allmask;
+        sX[lane] = (uint8_t)(ran ? V : C);
+        const bool need = (Lmax >= 1) && (e > thr);
+        const unsigned long long hard = __ballot(need);
+        if (hard != 0ull) {
+            const int ord = n_used + n_over + __popcll(hard & lt);
+            const bool slotted = need && ord < NSLOT;
+            if (need && !slotted) sOver[ord - NSLOT] = (uint8_t)(t * 64 + lane);
+            slot_t &s = slots[slotted ? ord : 0];
+            if (slotted) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) s.N[i] = N[i];
+                s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
+                s.nan = nanmask; s.zero = zeromask; s.unit = (tile << 6) + (uint32_t)lane;
+            }
+            // the third read, by the lanes that park a unit
+            asm volatile("" : "+v"(ub2));
+            load_half<T, EXACT>(a, C, ub2, uk, 0, h0);
+            if (slotted) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s.o[3 * i] = h0.x[i]; s.o[3 * i + 1] = h0.y[i]; s.o[3 * i + 2] = h0.w[i]; }
+            }
+            asm volatile("" : "+v"(ub2));
+            load_half<T, EXACT>(a, C, ub2, uk, 8, h0);
+            if (slotted) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s.o[24 + 3 * i] = h0.x[i]; s.o[24 + 3 * i + 1] = h0.y[i]; s.o[24 + 3 * i + 2] = h0.w[i]; }
+            }
+            const int tot = n_used + n_over + __popcll(hard);
+            n_over = max(0, tot - NSLOT);
+            n_used = min(NSLOT, tot);
+        }
+        wsync();
+        store_tile(tile);
+    };
+
     RegObs<T, CT> obs0, obs1, obs2, obs3;
     obs0.lik_thr = a.lik_thr; obs1.lik_thr = a.lik_thr; obs2.lik_thr = a.lik_thr; obs3.lik_thr = a.lik_thr;
     bool act0, act1 = false, act2 = false, act3 = false;
-    const uint32_t u0 = unit_of(tile0, act0);
-    load_obs<T, CT, EXACT>(a, C, u0 / (uint32_t)K, u0 % (uint32_t)K, obs0);
+    if constexpr (CT <= 8) {
+        const uint32_t u0 = unit_of(tile0, act0);
+        load_obs<T, CT, EXACT>(a, C, u0 / (uint32_t)K, u0 % (uint32_t)K, obs0);
+    } else {
+        act0 = false;
+    }
     const bool two = my_tiles > 1 && tile0 + tstride < n_tiles;
     const bool three = TPW > 2 && my_tiles > 2 && tile0 + 2 * tstride < n_tiles;
     const bool four = TPW > 3 && my_tiles > 3 && tile0 + 3 * tstride < n_tiles;
@@ -594,6 +744,11 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             load_obs<T, CT, EXACT>(a, C, u / (uint32_t)K, u % (uint32_t)K, obs);
         }
     };
+    if constexpr (CT > 8) {
+        level0_wide(0);
+        if constexpr (TPW > 1) { if (two) level0_wide(1); }
+        if constexpr (TPW > 2) { if (three) level0_wide(2); }
+    } else {
     level0(0, act0, obs0, [&](double dep) { if constexpr (TPW > 1) request(two, 1, act1, obs1, dep); });
     if constexpr (TPW > 1) {
         if (two) level0(1, act1, obs1, [&](double dep) { if constexpr (TPW > 2) request(three, 2, act2, obs2, dep); });
@@ -603,6 +758,7 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
     }
     if constexpr (TPW > 3) {
         if (four) level0(3, act3, obs3, [](double) {});
+    }
     }
 
     // ---- camera-subset search over the pooled units; their results are patched over what their tiles stored --------------
@@ -646,11 +802,12 @@ hipError_t launch_pool(P2sTriArgs a, int singles_pct, hipStream_t s) {
 
 bool p2s_tri_pool_supports(int C, int dtype, int undistort, int lr_swap) {
     if (undistort || lr_swap) return false;
-    return dtype == 0 ? C <= 8 : false;
+    return dtype == 0 ? C <= 16 : false;
 }
 
 hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int dtype, int singles_pct, int tiles_per_wave, hipStream_t s) {
     (void)dtype;
+    if (a.C > 8) return launch_pool<float, 16, 20, 2>(a, singles_pct, s);
     if (a.C <= 4) return launch_pool<float, 4, 32, 3>(a, singles_pct, s);
     if (tiles_per_wave == 2) return launch_pool<float, 8, 32, 2>(a, singles_pct, s);
     if (tiles_per_wave == 4) return launch_pool<float, 8, 32, 4>(a, singles_pct, s);
