@@ -392,9 +392,11 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                             auto downdate = [&](const bool go, const uint32_t Rreal) -> Base {
                                 Base b = base;
                                 for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                                    // (a lane with nothing left to remove goes through the motions on one of its unit's valid
+                                    // cameras with weight 0: finite numbers, loads without branches)
                                     const bool on = rr != 0u;
-                                    const int c = on ? __builtin_ctz(rr) : 0;
-                                    const float x = on ? (float)s.o[3 * c] : 0.0f, y = on ? (float)s.o[3 * c + 1] : 0.0f;
+                                    const int c = __builtin_ctz(on ? rr : o_valid);
+                                    const float x = (float)s.o[3 * c], y = (float)s.o[3 * c + 1];
                                     const float w = on ? (float)s.o[3 * c + 2] : 0.0f;
                                     const float *P = sPf + c * 12;
                                     const float A0 = fmaf(-x, P[8], P[0]), A1 = fmaf(-x, P[9], P[1]), A2 = fmaf(-x, P[10], P[2]), A3 = fmaf(-x, P[11], P[3]);
@@ -569,7 +571,24 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
 #pragma unroll
         for (int i = 0; i < 10; ++i) N[i] = 0.0;
         uint32_t nanmask = 0, zeromask = 0;
-        classify_and_accumulate<T, CT>(cams, C, cur, N, nanmask, zeromask);
+        // classify_and_accumulate / mean_error of p2s_tri_dev.h with two instruction-count savings (same arithmetic, same
+        // bits): a camera that does not count is zeroed once, in single precision, and everything after -- normal matrix,
+        // reprojection pass (its distance is masked anyway), the unit's slot -- reads the zeroed copy (3 selects per camera
+        // instead of 6 on the converted values); a degenerate camera shows as a NaN in the sum instead of being looked for
+        // camera by camera.
+        RegObs<T, CT> obs;
+        obs.lik_thr = a.lik_thr;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const T x = cur.x[c], y = cur.y[c], w = cur.w[c];
+            const bool isn = (EXACT || c < C) && (!(w == w) || ((double)w < a.lik_thr));
+            const bool isz = (EXACT || c < C) && (w == (T)0) && !isn;
+            nanmask |= isn ? (1u << c) : 0u;
+            zeromask |= isz ? (1u << c) : 0u;
+            const bool okc = (EXACT || c < C) && !(isn || isz);
+            obs.x[c] = okc ? x : (T)0; obs.y[c] = okc ? y : (T)0; obs.w[c] = okc ? w : (T)0;
+            if (EXACT || c < C) accum_camera<1>(N, cams[c].P, (double)obs.x[c], (double)obs.y[c], (double)obs.w[c]);
+        }
         const uint32_t dmask = nanmask | zeromask;
         const uint32_t valid = allmask & ~dmask;
         const int V = __popc(dmask);
@@ -578,7 +597,33 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         smallest_eigvec(N, q);
         prefetch(q[0]);
         if (C - V < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }  // common.py:347: fewer than 4 rows
-        const double e = mean_error<T, false, CT>(cams, C, cur, valid, q);
+        double e;
+        {
+            double sum = 0.0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                if (EXACT || c < C) {
+                    bool reg;
+                    const double d = camera_distance<false>(cams + c, q, (double)obs.x[c], (double)obs.y[c], reg);
+                    sum += ((valid >> c) & 1u) ? d : 0.0;
+                }
+            }
+            // a wanted camera with s z^2 not in (0, inf) left a NaN behind (its reciprocal square root): such units take the
+            // literal formula with the reference's NaN rules (all-NaN -> inf, nansum)
+            const bool irregular = sum != sum;
+            if (__any(irregular)) {
+                double sum2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (EXACT || c < C) {
+                        const double d = camera_distance_exact(cams + c, q[0], q[1], q[2], (double)obs.x[c], (double)obs.y[c]);
+                        sum2 += ((valid >> c) & 1u) ? d : 0.0;
+                    }
+                }
+                sum = irregular ? sum2 : sum;
+            }
+            e = sum * fast_rcp((double)__popc(valid));                     // no camera kept -> NaN, as np.mean([])
+        }
         const bool ran = Lmax >= 0;                                        // else no level completes (:595-596)
         const bool ok = ran && (e <= thr);                                 // :600-602
         if (t > 0) wsync();                                                // the previous tile's staged results have left
@@ -593,7 +638,7 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         const unsigned long long hard = __ballot(need);
         if (need) {
             const int ord = n_used + n_over + __popcll(hard & lt);
-            if (ord < NSLOT) fill_slot(slots[ord], N, q, nanmask, zeromask, (tile << 6) + (uint32_t)lane, cur);
+            if (ord < NSLOT) fill_slot(slots[ord], N, q, nanmask, zeromask, (tile << 6) + (uint32_t)lane, obs);
             else sOver[ord - NSLOT] = (uint8_t)(t * 64 + lane);
         }
         {
