@@ -157,6 +157,55 @@ def bench_association(args, cfg, rank, world, local_rank):
                         'note': 'LDS-resident fp64 Jacobi iteration, bound by vector instruction issue: achieved = fp64 operations '
                                 'counted by the kernel (p2s_get_assoc_stats) / time, peak = fp64 vector peak; HBM traffic is ~10 KB per '
                                 '~1e7 flop and not the bound (SURVEY 8d)'}}
+    # ---- the rest of BASELINE configs[2] ("association then triangulation"): the triangulation of the 4 persons'
+    # 5.2 M units (triangulation.py:831-865 over P = 4), and the stage with its host half -- affinity matrices back to the
+    # host and proposal extraction (personAssociation.py:512-549: the per-detection argmax natively, the order-deciding
+    # NumPy calls per frame) -- on a bounded sample of the frames
+    from pose2sim_amd import personAssociation as pa_mod, skeletons, synth_device
+    ids, names, swap_list = skeletons.keypoints(cfg['model'])
+    Pn = cfg['Pn']
+    n_blocks, n_units = F * Pn, F * Pn * K
+    d_xyl = synth_device.make_observations_device(cams, F, Pn, K, seed=cfg['seed'] + 977 * rank, device=dev)
+    tprm = Engine.tri_params(cfg['thr'], cfg['lik'], cfg['min_cams'], False, False)
+    d_Q = torch.empty((n_units, 3), dtype=torch.float64, device=dev)
+    d_e = torch.empty(n_units, dtype=torch.float32, device=dev)
+    d_m = torch.empty(n_units, dtype=torch.int32, device=dev)
+    d_x = torch.empty(n_units, dtype=torch.uint8, device=dev)
+    d_swap = torch.from_numpy(np.asarray(swap_list, dtype=np.int32)).to(dev)
+
+    def tri_step():
+        eng.triangulate_device(n_blocks, K, P2S_F32, d_xyl, d_swap, tprm, d_Q.data_ptr(), d_e.data_ptr(), d_x.data_ptr(), d_m.data_ptr())
+    for _ in range(3):
+        tri_step()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n_tri = max(5, args.steps)
+    ev0.record()
+    for _ in range(n_tri):
+        tri_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    tri_ms = ev0.elapsed_time(ev1) / n_tri
+    tri_bytes = n_units * (12 * C + 32)
+    out['triangulation_leg'] = {'units': n_units, 'kernel_ms': tri_ms, 'units_per_s': n_units / (tri_ms * 1e-3),
+                                'roofline': {'bound': 'hbm', 'achieved': tri_bytes / (tri_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                             'frac': tri_bytes / (tri_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_unit': 12 * C + 32},
+                                'note': 'p2s_triangulate_device on the 4 persons of every frame (device-generated observations of the same shape)'}
+    assoc_ms = dt / args.steps * 1e3
+    out['association_plus_triangulation'] = {'frames_per_s': F / ((assoc_ms + tri_ms) * 1e-3), 'ms_per_50k_frames': assoc_ms + tri_ms,
+                                             'note': 'both kernels, inputs resident in HBM'}
+    n_e2e = min(F, args.e2e_frames)
+    t0 = time.perf_counter()
+    eng.associate_device(n_e2e, K, n_max, P2S_F32, d_np, d_off, d_kp, prm, d_aff)
+    torch.cuda.synchronize()
+    aff_host = d_aff[:n_e2e].cpu().numpy()
+    t1 = time.perf_counter()
+    props = pa_mod.proposals_batch(aff_host, n_persons[:n_e2e], cfg['min_cams'])
+    t2 = time.perf_counter()
+    out['stage_with_host_half'] = {'frames': n_e2e, 'frames_per_s': n_e2e / (t2 - t0), 'kernel_and_copy_s': t1 - t0, 'proposals_s': t2 - t1,
+                                   'mean_proposals_per_frame': float(np.mean([len(p) for p in props])),
+                                   'note': 'association kernel + affinity matrices to the host + proposal extraction (native argmax rows, '
+                                           'then the reference\'s np.unique / np.argsort per frame); JSON reading and rewriting not included '
+                                           '(profiles/e2e_assoc_bench.py times the stage on files)'}
     if not args.no_cpu_baseline:
         from oracle import association_ref as ar
         cal = {'inv_K': cams['inv_K'], 'R_mat': cams['R_mat'], 'T': cams['T']}
@@ -346,7 +395,7 @@ def cpu_baselines(cfg, frames_1core, frames_all):
 # (first pass ~95, later passes ~115 at 1.1 later passes on average), the reprojection distance of one camera
 # (9 FMA projection, 4 FMA / multiply residuals, 2 for s z^2, reciprocal square root with one Newton step, sum).
 FLOP_ACC_PER_CAM, FLOP_EIGEN, FLOP_ERR_PER_CAM = 66, 220, 36
-FP64_PEAK = 78.6e12                                # MI355X fp64 vector (= matrix) peak, MI355X_MICROARCH.md
+FP64_PEAK = 78.6e12                                # MI355X fp64 vector (= matrix) peak: AMD's published spec (the guide has no fp64 row; a bare v_fma_f64 loop reaches 66.6, exp/mfma_valu_overlap.hip)
 
 
 def fp64_flops_per_step(n_units, C, stats_per_step):
@@ -408,6 +457,7 @@ def main():
     ap.add_argument('--no-screen', action='store_true', help='kernel experiments: pooled kernel without its fp32 screen (P2S_TUNE_SCREEN 0)')
     ap.add_argument('--pool-tiles', type=int, default=0, help='kernel experiments: P2S_TUNE_POOL_TILES')
     ap.add_argument('--cpu-frames', type=int, default=0, help='frames for the cpu_baseline sample (0 = auto)')
+    ap.add_argument('--e2e-frames', type=int, default=10_000, help='cfg3: frames of the association stage timed with its host half')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -589,11 +639,19 @@ def main():
         alg_bytes = n_units * (12 * C + 32)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         flops = fp64_flops_per_step(n_units, C, stats)
-        traffic = None
+        # HBM bytes per step as counted by rocprofv3 (profiles/collect.sh): reported only while the kernel sources are the
+        # ones the counters were taken on (profiles/summarize.py keeps their fingerprint beside the figure)
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config)
+                import hashlib
+                entry_t = json.load(open(tpath)).get(args.config)
+                h = hashlib.sha1()
+                for name in ('p2s_tri_pool.hip', 'p2s_tri_fused.hip', 'p2s_tri.hip', 'p2s_tri_deep.hip', 'p2s_tri_dev.h', 'p2s_internal.h', 'p2s_api.hip'):
+                    h.update(open(os.path.join(ROOT, 'pose2sim_amd', 'csrc', name), 'rb').read())
+                if isinstance(entry_t, dict) and entry_t.get('sources_sha1') == h.hexdigest() and args.tri_path == 'auto':
+                    traffic, traffic_source = entry_t['bytes_per_step'], entry_t.get('source')
             except Exception:
                 traffic = None
         fused = (not cfg['undistort']) and (not cfg['lr_swap']) and C <= 16
@@ -617,10 +675,15 @@ def main():
                                   'capped_units_per_step': stats['capped_units']},
                        'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'fp64_frac': flops / (k_ms * 1e-3) / FP64_PEAK, 'fp64_tflops': flops / (k_ms * 1e-3) / 1e12,
                          'fp64_flop_per_step': flops,
-                         'kernel': ('p2s_tri_fused_kernel (streaming pass + in-wave subset search of the wave\'s pooled failures, one launch)'
+                         # the screen's single-precision work (not in fp64_frac): per subset looked at, the downdate of ~1.2
+                         # cameras (84 each), three 3x3 solves and two Rayleigh quotients (~290), C reprojection distances (~40)
+                         'screen_fp32_flop_per_step': stats.get('screened_subsets', 0.0) * (1.2 * 84 + 290 + 40 * C),
+                         'kernel': ('p2s_tri_pool_kernel (streaming pass, failures of 3 tiles pooled, fp32 screen + fp64 evaluation of the surviving camera subsets, one launch)'
+                                    if (fused and args.tri_path in ('auto', 'pooled')) else
+                                    'p2s_tri_fused_kernel (round 2: streaming pass + in-wave fp64 subset search, one launch)'
                                     if (fused and args.tri_path != 'worklist') else
                                     'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)'),
                          'kernel_ms': k_ms, 'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},

@@ -34,6 +34,9 @@
 
 namespace {
 
+#ifndef P2S_POOL_SLOTS4
+#define P2S_POOL_SLOTS4 32
+#endif
 #ifndef P2S_POOL_WPS
 #define P2S_POOL_WPS 3          // waves per SIMD the register allocation aims at
 #endif
@@ -855,6 +858,6 @@ hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int dtype, int singles_pct, 
     if (a.C > 8) return launch_pool<float, 16, 20, 2>(a, singles_pct, s);
     if (a.C <= 4) return launch_pool<float, 4, 32, 3>(a, singles_pct, s);
     if (tiles_per_wave == 2) return launch_pool<float, 8, 32, 2>(a, singles_pct, s);
-    if (tiles_per_wave == 4) return launch_pool<float, 8, 32, 4>(a, singles_pct, s);
+    if (tiles_per_wave == 4) return launch_pool<float, 8, P2S_POOL_SLOTS4, 4>(a, singles_pct, s);
     return launch_pool<float, 8, 32, 3>(a, singles_pct, s);
 }
