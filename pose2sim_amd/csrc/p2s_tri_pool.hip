@@ -37,6 +37,12 @@ namespace {
 #ifndef P2S_POOL_SLOTS4
 #define P2S_POOL_SLOTS4 32
 #endif
+#ifndef P2S_POOL_WIDE_REREAD
+#define P2S_POOL_WIDE_REREAD 0       // 9-16 cameras: 1 = x and y are read again for the reprojection pass instead of kept (32 registers)
+#endif
+#ifndef P2S_POOL_WIDE_STREAM
+#define P2S_POOL_WIDE_STREAM 0
+#endif
 #ifndef P2S_POOL_WPS
 #define P2S_POOL_WPS 3          // waves per SIMD the register allocation aims at
 #endif
@@ -87,7 +93,7 @@ __device__ __forceinline__ void load_obs(const P2sTriArgs &a, int C, uint32_t b,
 
 // Cameras c0 .. c0 + 7 of one unit (the 9-16 camera kernels work on the observations eight cameras at a time: 48 registers
 // of observations beside the eigen-solve spilled ~400 B per lane in round 2).
-template <typename T, bool EXACT, bool WITH_W = true>
+template <typename T, bool EXACT, bool WITH_W = true, bool STREAM = true>
 __device__ __forceinline__ void load_half(const P2sTriArgs &a, int C, uint32_t b, uint32_t k, int c0, RegObs<T, 8> &obs) {
     const unsigned char *chunk = reinterpret_cast<const unsigned char *>(a.xyl) +
                                  (size_t)a.block0 * (size_t)C * (size_t)a.K * 3u * sizeof(T);
@@ -97,9 +103,15 @@ __device__ __forceinline__ void load_half(const P2sTriArgs &a, int C, uint32_t b
     for (int i = 0; i < 8; ++i) {
         if (EXACT || c0 + i < C) {
             const T *p = reinterpret_cast<const T *>(chunk + (size_t)(c0 + i) * cam_stride + voff);
-            obs.x[i] = __builtin_nontemporal_load(p);
-            obs.y[i] = __builtin_nontemporal_load(p + 1);
-            obs.w[i] = WITH_W ? __builtin_nontemporal_load(p + 2) : (T)0;
+            if (STREAM) {
+                obs.x[i] = __builtin_nontemporal_load(p);
+                obs.y[i] = __builtin_nontemporal_load(p + 1);
+                obs.w[i] = WITH_W ? __builtin_nontemporal_load(p + 2) : (T)0;
+            } else {                                               // read again later: let the caches keep the lines
+                obs.x[i] = p[0];
+                obs.y[i] = p[1];
+                obs.w[i] = WITH_W ? p[2] : (T)0;
+            }
         } else {
             obs.x[i] = obs.y[i] = obs.w[i] = (T)0;
         }
@@ -662,8 +674,8 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         const uint32_t ub = u / (uint32_t)K, uk = u % (uint32_t)K;
         RegObs<T, 8> h0, h1;
         h0.lik_thr = a.lik_thr; h1.lik_thr = a.lik_thr;
-        load_half<T, EXACT>(a, C, ub, uk, 0, h0);
-        load_half<T, EXACT>(a, C, ub, uk, 8, h1);
+        load_half<T, EXACT, true, P2S_POOL_WIDE_STREAM != 0>(a, C, ub, uk, 0, h0);
+        load_half<T, EXACT, true, P2S_POOL_WIDE_STREAM != 0>(a, C, ub, uk, 8, h1);
         double N[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) N[i] = 0.0;
@@ -691,8 +703,10 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         double q[3];
         smallest_eigvec(N, q);
         uint32_t ub2 = ub;
+#if P2S_POOL_WIDE_REREAD
         asm volatile("" : "+v"(ub2) : "v"(q[0]));                          // the second read not before the eigen-solve
         load_half<T, EXACT, false>(a, C, ub2, uk, 0, h0);                  // x and y only
+#endif
         if (C - V < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
         double sum = 0.0;
         bool irregular = false;
@@ -709,9 +723,13 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             }
         };
         distances(0, h0);
+#if P2S_POOL_WIDE_REREAD
         asm volatile("" : "+v"(ub2));                                      // (addresses are recomputed, not kept: 2 registers per camera)
         load_half<T, EXACT, false>(a, C, ub2, uk, 8, h0);
         distances(8, h0);
+#else
+        distances(8, h1);
+#endif
         if (__any(irregular)) {                                            // rare: some wanted camera is degenerate / NaN
             double sum2 = 0.0;
             auto exact = [&](const int c0, const RegObs<T, 8> &h) {
@@ -723,10 +741,15 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     }
                 }
             };
+#if P2S_POOL_WIDE_REREAD
             load_half<T, EXACT, false>(a, C, ub2, uk, 0, h0);
             exact(0, h0);
             load_half<T, EXACT, false>(a, C, ub2, uk, 8, h0);
             exact(8, h0);
+#else
+            exact(0, h0);
+            exact(8, h1);
+#endif
             sum = irregular ? sum2 : sum;
         }
         const double e = sum * fast_rcp((double)__popc(valid));
@@ -752,16 +775,14 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                 s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
                 s.nan = nanmask; s.zero = zeromask; s.unit = (tile << 6) + (uint32_t)lane;
             }
-            // the third read, by the lanes that park a unit
-            asm volatile("" : "+v"(ub2));
-            load_half<T, EXACT>(a, C, ub2, uk, 0, h0);
+            // another read, by the lanes that park a unit only (they need the likelihoods again)
             if (slotted) {
+                asm volatile("" : "+v"(ub2));
+                load_half<T, EXACT>(a, C, ub2, uk, 0, h0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s.o[3 * i] = h0.x[i]; s.o[3 * i + 1] = h0.y[i]; s.o[3 * i + 2] = h0.w[i]; }
-            }
-            asm volatile("" : "+v"(ub2));
-            load_half<T, EXACT>(a, C, ub2, uk, 8, h0);
-            if (slotted) {
+                asm volatile("" : "+v"(ub2));
+                load_half<T, EXACT>(a, C, ub2, uk, 8, h0);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { s.o[24 + 3 * i] = h0.x[i]; s.o[24 + 3 * i + 1] = h0.y[i]; s.o[24 + 3 * i + 2] = h0.w[i]; }
             }
