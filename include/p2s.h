@@ -218,13 +218,19 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
 
 /* Experiments and tests only -- apart from P2S_TUNE_MAX_SUBSETS nothing here changes a result, and the library never
  * reads the environment.
- *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the one-launch kernel with the in-wave subset search where it
- *                         applies (pinhole, no L/R swap, up to 16 cameras; two tiles per wave with pooled searching units
- *                         for float32 input and up to 8 cameras), else the streaming + work-list search pair;
- *                         P2S_TRI_PATH_ONE_TILE: the one-launch kernel with one tile per wave everywhere;
+ *   P2S_TUNE_TRI_PATH     P2S_TRI_PATH_AUTO (default): the pooled one-launch kernel (failures of three tiles pooled, fp32
+ *                         screen + fp64 evaluation of the surviving camera subsets) where it applies (pinhole, no L/R swap,
+ *                         float32 observations, up to 16 cameras), else round 2's one-launch kernel (float64 observations,
+ *                         up to 8 cameras), else the streaming + work-list search pair;
+ *                         P2S_TRI_PATH_POOLED: the same choice (named, for tests); P2S_TRI_PATH_TWO_TILES / _ONE_TILE: round
+ *                         2's one-launch kernel with two tiles per wave where it pools / one tile everywhere;
  *                         P2S_TRI_PATH_WORKLIST: always the pair
+ *   P2S_TUNE_SCREEN       0: the pooled kernel sends every camera subset to the fp64 evaluation (default 1: only those
+ *                         its fp32 screen cannot rule out; same results bit for bit)
+ *   P2S_TUNE_POOL_TILES   tiles of 64 units a wave of the pooled kernel streams before it searches their failures (2..4,
+ *                         default 3; 9-16 cameras: 2)
  *   P2S_TUNE_POOL_SINGLES_PCT  share (%) of the tiles that the last workgroups of every XCD take one at a time instead
- *                         of two (default 8)
+ *                         of several (default 8)
  *   P2S_TUNE_FORCE_TILED  1: the LDS-tiled streaming kernel even where observations fit in registers
  *   P2S_TUNE_NO_OVERLAP   1: search kernels on the main stream instead of beside the next chunk's streaming pass
  *   P2S_TUNE_SEARCH_JOB   work-list records a search wave takes at a time (8..64; 0 = automatic)

@@ -1,16 +1,15 @@
-// p2s_tri_pool.hip -- one-launch robust triangulation for gfx950 (MI355X, CDNA4), round 3: persistent waves that stream
-// tile after tile, POOL the units whose level-0 error exceeds the threshold in LDS slots across tiles, and search their
+// p2s_tri_pool.hip -- one-launch robust triangulation for gfx950 (MI355X, CDNA4), round 3: a wave streams a few tiles of
+// 64 units, POOLS the units whose level-0 error exceeds the threshold in LDS slots across its tiles, and searches their
 // camera subsets (triangulation_from_best_cameras, triangulation.py:363-604) in two tiers:
 //
-//   tier A (screen, fp32): every candidate subset of a level is evaluated in single precision in coordinates centred on
-//     the unit's level-0 point -- normal matrix of the kept cameras by downdate, smallest eigenpair by two Rayleigh
-//     steps, mean reprojection error -- at about half the issue cost of the fp64 evaluation (exp/valu_rates.hip: a
-//     wave64 v_fma_f32 holds the SIMD ~2.9 cycles, a v_fma_f64 ~5.4).  It decides nothing by itself: a candidate is dropped
-//     only if its fp32 error, minus a margin that is 30x the largest deviation from the fp64 error seen on any workload
-//     (exp/screen_proto.py, tests/sweeps), cannot be the level's minimum and -- on a level that is not the unit's last,
-//     so that a failed level leaves nothing behind -- cannot be under the threshold.  Candidates the screen cannot vouch
-//     for (ill-conditioned system, eigen-iteration not settled, irregular projection, level-0 point far away or not
-//     finite) always go on.
+//   tier A (screen, fp32, two subsets per lane in packed registers): every candidate subset of a level is evaluated in
+//     single precision in coordinates centred on the unit's level-0 point -- normal matrix of the kept cameras by
+//     downdate, smallest eigenpair by two Rayleigh steps, mean reprojection error.  It decides nothing by itself: a
+//     candidate is dropped only if its fp32 error, minus a margin that is 30x the largest deviation from the fp64 error
+//     seen on any workload (exp/screen_proto.py, tests/sweeps), cannot be the level's minimum and -- on a level that is
+//     not the unit's last, so that a failed level leaves nothing behind -- cannot be under the threshold.  Candidates
+//     the screen cannot vouch for (ill-conditioned system, eigen-iteration not settled, degenerate projection, level-0
+//     point far away or not finite) always go on.
 //   tier B (fp64): the survivors -- 0.93 per searching unit on BASELINE configs[1] instead of 8 -- of ALL the pooled
 //     units and levels are evaluated together, one per lane, by exactly the arithmetic of level 0; the argmin per unit
 //     (error, then rank: np.nanargmin's first index) goes through LDS atomics.
@@ -19,12 +18,17 @@
 // serves the survivors of several levels.  Every number that reaches a result comes from tier B: with the screen switched
 // off (P2S_TUNE_SCREEN 0: every candidate survives) the outputs are bit-identical (tests/test_tri_gpu.py).
 //
-// Why persistent: a wave that streams two tiles has 15 searching units; their level-1 candidates fill 2 screen passes
-// but their survivors only a quarter of one fp64 pass.  Here the slots fill up over ~3 tiles before a search runs, the
-// results of a tile leave at once (16-byte stores) and the searched units' results are patched afterwards.
+// The results of a tile leave the wave as soon as its level 0 is through (16-byte stores); the searched units' results
+// are patched over them after the search.  That takes the results' staging out of the LDS budget, so a wave can pool
+// three tiles (23 searching units on configs[1]) where round 2's kernel pooled two; the tiles are taken in straight-line
+// code, fresh waves by the dispatcher: a persistent loop over tiles streamed 15-60 % slower.
 //
-// Scope: pinhole path without L/R swap (both off in every shipped configuration), up to 16 cameras
-// (8 for float64 input); everything else takes the kernels of p2s_tri.hip.
+// 9-16 cameras: the observations are taken eight cameras at a time (48 registers of them beside the eigen-solve
+// spilled); x and y stay in registers for the reprojection pass, the lanes that park a unit read theirs again.
+//
+// Scope: pinhole path without L/R swap (both off in every shipped configuration), float32 observations,
+// up to 16 cameras; float64 observations take round 2's one-launch kernel (p2s_tri_fused.hip), everything else the
+// kernels of p2s_tri.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
