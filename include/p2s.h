@@ -341,6 +341,18 @@ int p2s_json_rewrite_people(const char *src_paths, const int64_t *src_offsets, c
 int p2s_assoc_argmax_rows(int64_t n_frames, int32_t n_cams, int32_t n_max, const double *affinity, const int32_t *n_persons,
                           int32_t n_threads, int32_t *rows);
 
+/* Proposals, second half (personAssociation.py:528-549), every frame at once, around the one call whose result is not
+ * specified -- np.argsort of the multiplicities, which the caller makes itself on the array the reference would pass:
+ *   p2s_assoc_unique_rows: np.unique(rows, axis=0, return_counts=True) per frame: uniq [F][n_max][C] (the distinct rows of
+ *     rows[f][0 .. n_rows[f]) in lexicographic order), counts [F][n_max] int64, n_uniq [F];
+ *   p2s_assoc_filter_rows: with rank[f][i] = index of the i-th ranked distinct row (np.argsort(counts)[::-1]): the
+ *     first-come filter (a row that names, for some camera, a person named by ANY row ranked before it is dropped) and the
+ *     minimum number of cameras; props [F][n_max][C] (-1 = the reference's NaN), n_props [F]. */
+int p2s_assoc_unique_rows(int64_t n_frames, int32_t n_cams, int32_t n_max, const int32_t *rows, const int32_t *n_rows,
+                          int32_t n_threads, int32_t *uniq, int64_t *counts, int32_t *n_uniq);
+int p2s_assoc_filter_rows(int64_t n_frames, int32_t n_cams, int32_t n_max, const int32_t *uniq, const int32_t *n_uniq,
+                          const int32_t *rank, int32_t min_cams, int32_t n_threads, int32_t *props, int32_t *n_props);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,8 @@ SIGNATURES = {
     'p2s_json_gather_people': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                          C.c_void_p, C.POINTER(C.c_int64)]),
     'p2s_assoc_argmax_rows': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    'p2s_assoc_unique_rows': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'p2s_assoc_filter_rows': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     'p2s_json_rewrite_people': (C.c_int, [C.c_char_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_void_p]),
     'p2s_trc_append_rows': (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),

@@ -84,14 +84,12 @@ __device__ __forceinline__ void load_obs(const P2sTriArgs &a, int C, uint32_t b,
     const uint32_t cam_stride = (uint32_t)a.K * (uint32_t)(3 * sizeof(T));
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
-        if (EXACT || c < C) {
-            const T *p = reinterpret_cast<const T *>(chunk + (size_t)c * cam_stride + voff);
-            obs.x[c] = __builtin_nontemporal_load(p);
-            obs.y[c] = __builtin_nontemporal_load(p + 1);
-            obs.w[c] = __builtin_nontemporal_load(p + 2);
-        } else {
-            obs.x[c] = obs.y[c] = obs.w[c] = (T)0;
-        }
+        // (a camera beyond C reads camera 0's address and is zeroed: loads under a branch made the compiler keep the
+        // whole structure in scratch memory in the kernels compiled for a range of camera counts)
+        const bool there = EXACT || c < C;
+        const T *p = reinterpret_cast<const T *>(chunk + (size_t)(there ? c : 0) * cam_stride + voff);
+        const T x = __builtin_nontemporal_load(p), y = __builtin_nontemporal_load(p + 1), w = __builtin_nontemporal_load(p + 2);
+        obs.x[c] = there ? x : (T)0; obs.y[c] = there ? y : (T)0; obs.w[c] = there ? w : (T)0;
     }
 }
 
@@ -105,20 +103,17 @@ __device__ __forceinline__ void load_half(const P2sTriArgs &a, int C, uint32_t b
     const uint32_t cam_stride = (uint32_t)a.K * (uint32_t)(3 * sizeof(T));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (EXACT || c0 + i < C) {
-            const T *p = reinterpret_cast<const T *>(chunk + (size_t)(c0 + i) * cam_stride + voff);
-            if (STREAM) {
-                obs.x[i] = __builtin_nontemporal_load(p);
-                obs.y[i] = __builtin_nontemporal_load(p + 1);
-                obs.w[i] = WITH_W ? __builtin_nontemporal_load(p + 2) : (T)0;
-            } else {                                               // read again later: let the caches keep the lines
-                obs.x[i] = p[0];
-                obs.y[i] = p[1];
-                obs.w[i] = WITH_W ? p[2] : (T)0;
-            }
-        } else {
-            obs.x[i] = obs.y[i] = obs.w[i] = (T)0;
+        const bool there = EXACT || c0 + i < C;
+        const T *p = reinterpret_cast<const T *>(chunk + (size_t)(there ? c0 + i : 0) * cam_stride + voff);
+        T x, y, w = (T)0;
+        if (STREAM) {
+            x = __builtin_nontemporal_load(p); y = __builtin_nontemporal_load(p + 1);
+            if (WITH_W) w = __builtin_nontemporal_load(p + 2);
+        } else {                                                   // read again later: let the caches keep the lines
+            x = p[0]; y = p[1];
+            if (WITH_W) w = p[2];
         }
+        obs.x[i] = there ? x : (T)0; obs.y[i] = there ? y : (T)0; obs.w[i] = there ? w : (T)0;
     }
 }
 

@@ -69,8 +69,11 @@ def proposals_from_rows(rows, min_cameras_for_triangulation):
 
 
 def proposals_batch(affinity, n_persons, min_cameras_for_triangulation):
-    """person_index_per_cam for every frame: the per-detection argmax rows of all frames in one native call
-    (csrc/p2s_proposals.cpp, the Python double loop of :516-527), then the reference's NumPy calls per frame.
+    """person_index_per_cam for every frame (csrc/p2s_proposals.cpp): the per-detection argmax rows (the Python double
+    loop of :516-527), their distinct rows and multiplicities (np.unique, :530) and, after the ranking, the first-come and
+    minimum-camera filters (:534-546) are native, all frames at once.  The ranking itself -- np.argsort of the
+    multiplicities, whose order among equal counts is not specified and not stable in NumPy 2.x's SIMD sorts -- is the
+    reference's own call on the array the reference would pass (remembered per distinct array: a trial has a handful).
     affinity [F][n_max][n_max], n_persons [F][C] -> list of float arrays [n_proposals][C] (NaN = unseen)."""
     import ctypes as C
     from . import _lib
@@ -79,12 +82,35 @@ def proposals_batch(affinity, n_persons, min_cameras_for_triangulation):
     n_persons = np.ascontiguousarray(n_persons, dtype=np.int32)
     F, n_cams = n_persons.shape
     n_max = affinity.shape[1] if affinity.ndim == 3 else 0
+    if F == 0 or n_max == 0:
+        return [np.array([]) for _ in range(F)]
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)    # noqa: E731
     rows = np.full((F, n_max, n_cams), -1, dtype=np.int32)
-    if F and n_max:
-        ptr = lambda a: a.ctypes.data_as(C.c_void_p)    # noqa: E731
-        _lib.check(lib.p2s_assoc_argmax_rows(F, n_cams, n_max, ptr(affinity), ptr(n_persons), 0, ptr(rows)))
-    totals = n_persons.sum(axis=1)
-    return [proposals_from_rows(rows[f, :int(totals[f])].astype(float), min_cameras_for_triangulation) for f in range(F)]
+    _lib.check(lib.p2s_assoc_argmax_rows(F, n_cams, n_max, ptr(affinity), ptr(n_persons), 0, ptr(rows)))
+    totals = np.ascontiguousarray(n_persons.sum(axis=1), dtype=np.int32)
+    uniq = np.empty((F, n_max, n_cams), dtype=np.int32)
+    counts = np.zeros((F, n_max), dtype=np.int64)
+    n_uniq = np.zeros(F, dtype=np.int32)
+    _lib.check(lib.p2s_assoc_unique_rows(F, n_cams, n_max, ptr(rows), ptr(totals), 0, ptr(uniq), ptr(counts), ptr(n_uniq)))
+    rank = np.zeros((F, n_max), dtype=np.int32)
+    remembered = {}
+    for f in range(F):
+        n = int(n_uniq[f])
+        if n == 0:
+            continue
+        c = counts[f, :n]
+        key = c.tobytes()
+        order = remembered.get(key)
+        if order is None:
+            order = remembered[key] = np.argsort(c)[::-1].astype(np.int32)      # :531, the reference's call
+        rank[f, :n] = order
+    props = np.empty((F, n_max, n_cams), dtype=np.int32)
+    n_props = np.zeros(F, dtype=np.int32)
+    _lib.check(lib.p2s_assoc_filter_rows(F, n_cams, n_max, ptr(uniq), ptr(n_uniq), ptr(rank), int(min_cameras_for_triangulation), 0,
+                                         ptr(props), ptr(n_props)))
+    as_float = np.where(props < 0, np.nan, props.astype(np.float64))
+    empty = np.array([])
+    return [as_float[f, :n_props[f]] if n_props[f] else empty for f in range(F)]
 
 
 def rewrite_json_files(json_tracked_files_f, json_files_f, proposals, n_cams):
