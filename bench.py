@@ -203,9 +203,9 @@ def bench_association(args, cfg, rank, world, local_rank):
     t2 = time.perf_counter()
     out['stage_with_host_half'] = {'frames': n_e2e, 'frames_per_s': n_e2e / (t2 - t0), 'kernel_and_copy_s': t1 - t0, 'proposals_s': t2 - t1,
                                    'mean_proposals_per_frame': float(np.mean([len(p) for p in props])),
-                                   'note': 'association kernel + affinity matrices to the host + proposal extraction (native argmax rows, '
-                                           'then the reference\'s np.unique / np.argsort per frame); JSON reading and rewriting not included '
-                                           '(profiles/e2e_assoc_bench.py times the stage on files)'}
+                                   'note': 'association kernel + affinity matrices to the host + proposal extraction (argmax rows, distinct rows and '
+                                           'filters native for all frames, np.argsort of the multiplicities as the reference calls it); JSON reading '
+                                           'and rewriting not included (profiles/e2e_assoc_bench.py times the stage on files)'}
     if not args.no_cpu_baseline:
         from oracle import association_ref as ar
         cal = {'inv_K': cams['inv_K'], 'R_mat': cams['R_mat'], 'T': cams['T']}
