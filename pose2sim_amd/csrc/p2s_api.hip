@@ -88,7 +88,7 @@ struct p2s_ctx {
     int deep_prune = 1;                              // p2s_tri_deep.hip: exact pruning of the deep levels' evaluations
     int pool_singles_pct = 8;                        // p2s_tri_fused.hip: share of the tiles that the last workgroups take one at a time
     int screen = 1;                                  // p2s_tri_pool.hip: fp32 screen of the camera-subset candidates
-    int pool_tiles = 3;                              // p2s_tri_pool.hip: tiles a wave streams before it searches their pooled failures (2..4)
+    int pool_tiles = 5;                              // p2s_tri_pool.hip: tiles a wave streams before it searches their pooled failures (2..6)
 };
 
 namespace {
@@ -392,7 +392,7 @@ int p2s_set_tuning(p2s_ctx *ctx, int32_t key, int32_t value) {
         return P2S_OK;
     case P2S_TUNE_SCREEN: ctx->screen = value ? 1 : 0; return P2S_OK;
     case P2S_TUNE_POOL_TILES:
-        if (value < 2 || value > 4) return fail(P2S_ERR_INVALID_ARG, "tiles per wave outside [2, 4]");
+        if (value < 2 || value > 6) return fail(P2S_ERR_INVALID_ARG, "tiles per wave outside [2, 6]");
         ctx->pool_tiles = value;
         return P2S_OK;
     case P2S_TUNE_ASSOC_FORM:

@@ -53,12 +53,16 @@ namespace {
 constexpr uint32_t kNone = 0xffffffffu;
 constexpr float kInfF = __builtin_huge_valf();
 
+// Up to 8 cameras tier B builds a survivor's normal matrix from the unit's observations (8 cameras accumulated cost less
+// than the 80 bytes per slot that would keep level 0's matrix: slots are what limits the tiles a wave can pool); beyond
+// that it removes the subset's cameras from level 0's matrix, kept in the slot (with level 0's point: the screen's base is
+// then built when the search starts, not in the streaming part where registers are short).
+template <bool KEEP> struct SlotNormal { double N[10]; double q0[3]; };
+template <> struct SlotNormal<false> {};
 template <typename T, int CT>
-struct alignas(16) QSlot {
-    double N[10];                          // normal matrix of all valid cameras
-    double q[3];                           // level-0 point until the base below is built, then the verified best's point
+struct alignas(16) QSlot : SlotNormal<(CT > 8)> {
     unsigned long long ebits;              // verified best error of the current level (bits of a non-negative double), ~0 = none
-    T o[CT * 3];                           // x, y, likelihood per camera
+    T o[CT * 3];                           // x, y, likelihood per camera (a camera that does not count: zeros)
     float M[6], g[3], h, c0[3];            // screen base: normal matrix of all valid cameras about c0 (the level-0 point)
     uint32_t rank, S;                      // verified best: rank in itertools order (atomic min among equal errors), subset
     uint32_t nan, zero;
@@ -174,10 +178,11 @@ constexpr float kCondMin = 3e-3f, kDlamMax = 0.25f, kMargAbs = 0.02f, kMargRel =
 template <typename T, int CT, int NSLOT, bool EXACT, int TPW>
 __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2sTriArgs a) {
     typedef QSlot<T, CT> slot_t;
+    constexpr bool KEEPN = CT > 8;
     __shared__ __align__(16) unsigned char smem[sizeof(slot_t) * NSLOT];
-    __shared__ __align__(16) double sP[CT * 12];
+    __shared__ __align__(16) double sP[KEEPN ? CT * 12 : 1];
     __shared__ __align__(16) float sPf[CT * 12];
-    __shared__ uint8_t sOver[64 * TPW];                  // units that found no slot: (tile within the wave) * 64 + lane, in order
+    __shared__ uint16_t sOver[64 * TPW];                  // units that found no slot: (tile within the wave) * 64 + lane, in order
     // One region, two lives: the results of the tile being streamed, staged for its 16-byte stores -- and, while a search
     // runs (the tile's results have left by then), the list of pending slots and the survivors awaiting tier B.
     __shared__ __align__(16) unsigned char sShare[64 * 24 + 64 * 4 + 64 * 4 + 64];
@@ -213,7 +218,10 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
     const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const bool screen_on = a.screen != 0;
-    for (int i = lane; i < C * 12; i += 64) { sP[i] = a.cams[i / 12].P[i % 12]; sPf[i] = (float)a.cams[i / 12].P[i % 12]; }
+    for (int i = lane; i < C * 12; i += 64) {
+        sPf[i] = (float)a.cams[i / 12].P[i % 12];
+        if constexpr (KEEPN) sP[i] = a.cams[i / 12].P[i % 12];
+    }
 
     int n_used = 0, n_over = 0;                          // slots in use, units waiting in sOver (wave-uniform)
     uint32_t st_units = 0, st_evals = 0, st_passes = 0, st_screened = 0, st_spasses = 0;
@@ -223,12 +231,35 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         active = lu < n_units;
         return active ? (uint32_t)lu : (uint32_t)(t << 6);
     };
+    // A slot keeps what the screen needs of level 0 -- its base: N' = T^T N T about c0 = the level-0 point, in fp64 and
+    // then rounded (g and h are what is left of M c0 + b and c0.(M c0 + 2b) + c after cancellation) -- and the unit's
+    // observations; tier B builds its normal matrices from those.
+    auto build_base = [&](slot_t &s, const double N[10], const double q[3]) {
+        const double c0 = q[0], c1 = q[1], c2 = q[2];
+        const double g0 = fma(N[0], c0, fma(N[1], c1, fma(N[2], c2, N[3])));
+        const double g1 = fma(N[1], c0, fma(N[4], c1, fma(N[5], c2, N[6])));
+        const double g2 = fma(N[2], c0, fma(N[5], c1, fma(N[7], c2, N[8])));
+        const double hh = fma(c0, g0 + N[3], fma(c1, g1 + N[6], fma(c2, g2 + N[8], N[9])));
+        s.M[0] = (float)N[0]; s.M[1] = (float)N[1]; s.M[2] = (float)N[2];
+        s.M[3] = (float)N[4]; s.M[4] = (float)N[5]; s.M[5] = (float)N[7];
+        s.g[0] = (float)g0; s.g[1] = (float)g1; s.g[2] = (float)g2; s.h = (float)hh;
+        const bool centred = (c0 * c0 + c1 * c1 + c2 * c2) < (double)kCentreMax2;   // false for NaN
+        s.c0[0] = centred ? (float)c0 : __builtin_nanf(""); s.c0[1] = (float)c1; s.c0[2] = (float)c2;
+        s.ebits = ~0ull; s.rank = kNone; s.S = 0u; s.surv = 0u;
+    };
+    auto fill_head = [&](slot_t &s, const double N[10], const double q[3], uint32_t nanmask, uint32_t zeromask, uint32_t unit) {
+        s.nan = nanmask; s.zero = zeromask; s.unit = unit;
+        if constexpr (KEEPN) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s.N[i] = N[i];
+            s.q0[0] = q[0]; s.q0[1] = q[1]; s.q0[2] = q[2];
+        } else {
+            build_base(s, N, q);
+        }
+    };
     auto fill_slot = [&](slot_t &s, const double N[10], const double q[3], uint32_t nanmask, uint32_t zeromask, uint32_t unit,
                          const RegObs<T, CT> &obs) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i) s.N[i] = N[i];
-        s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
-        s.nan = nanmask; s.zero = zeromask; s.unit = unit;
+        fill_head(s, N, q, nanmask, zeromask, unit);
 #pragma unroll
         for (int c = 0; c < CT; ++c) { s.o[3 * c] = obs.x[c]; s.o[3 * c + 1] = obs.y[c]; s.o[3 * c + 2] = obs.w[c]; }
     };
@@ -243,21 +274,8 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             slot_t &mine = slots[own ? lane : 0];
             const uint32_t m_nan = mine.nan, m_d = mine.nan | mine.zero, m_valid = allmask & ~m_d;
             const int m_V = __popc(m_d), m_Lmax = C - a.min_cams - m_V;
-            if (own) {
-                // screen base: N' = T^T N T about c0 = the level-0 point (fp64, then rounded: g and h are what is left
-                // of M c0 + b and c0.(M c0 + 2b) + c after cancellation)
-                const double c0 = mine.q[0], c1 = mine.q[1], c2 = mine.q[2];
-                const double *N = mine.N;
-                const double g0 = fma(N[0], c0, fma(N[1], c1, fma(N[2], c2, N[3])));
-                const double g1 = fma(N[1], c0, fma(N[4], c1, fma(N[5], c2, N[6])));
-                const double g2 = fma(N[2], c0, fma(N[5], c1, fma(N[7], c2, N[8])));
-                const double hh = fma(c0, g0 + N[3], fma(c1, g1 + N[6], fma(c2, g2 + N[8], N[9])));
-                mine.M[0] = (float)N[0]; mine.M[1] = (float)N[1]; mine.M[2] = (float)N[2];
-                mine.M[3] = (float)N[4]; mine.M[4] = (float)N[5]; mine.M[5] = (float)N[7];
-                mine.g[0] = (float)g0; mine.g[1] = (float)g1; mine.g[2] = (float)g2; mine.h = (float)hh;
-                const bool centred = (c0 * c0 + c1 * c1 + c2 * c2) < (double)kCentreMax2;   // false for NaN
-                mine.c0[0] = centred ? (float)c0 : __builtin_nanf(""); mine.c0[1] = (float)c1; mine.c0[2] = (float)c2;
-                mine.ebits = ~0ull; mine.rank = kNone; mine.S = 0u; mine.surv = 0u;
+            if constexpr (KEEPN) {
+                if (own) build_base(mine, mine.N, mine.q0);
             }
             enum { ST_DONE = 0, ST_NEED_A = 1, ST_WAIT_B = 2 };
             int state = own ? ST_NEED_A : ST_DONE, mylevel = 1;
@@ -284,21 +302,36 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     const uint32_t Rreal = S & o_valid, kept = o_valid & ~Rreal;
                     const int nkept = __popc(kept);
                     SlotObs<T> sobs{s.o, a.lik_thr};
+                    // the projection matrices are scalar loads at their point of use: an opaque copy of the pointer keeps the
+                    // compiler from hoisting 192 SGPRs' worth of them out of the loops
+                    cam_cptr cams_here = cams;
+                    asm volatile("" : "+s"(cams_here));
                     double Ns[10];
+                    if constexpr (KEEPN) {
+                        // level 0's normal matrix less the subset's cameras
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) Ns[i] = s.N[i];
-                    for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
-                        const bool on = rr != 0u;
-                        const int c = on ? __builtin_ctz(rr) : 0;
-                        const T x = s.o[3 * c], y = s.o[3 * c + 1], w = s.o[3 * c + 2];
-                        accum_camera<-1>(Ns, sP + c * 12, (double)(on ? x : (T)0), (double)(on ? y : (T)0), (double)(on ? w : (T)0));
+                        for (int i = 0; i < 10; ++i) Ns[i] = s.N[i];
+                        for (uint32_t rr = go ? Rreal : 0u; __any(rr != 0u); rr &= rr - 1) {
+                            const bool on = rr != 0u;
+                            const int c = on ? __builtin_ctz(rr) : 0;
+                            const T x = s.o[3 * c], y = s.o[3 * c + 1], w = s.o[3 * c + 2];
+                            accum_camera<-1>(Ns, sP + c * 12, (double)x, (double)y, on ? (double)w : 0.0);
+                        }
+                    } else {
+                        // normal matrix of the kept cameras, as the reference builds it (:469-476) and as level 0 did
+#pragma unroll
+                        for (int i = 0; i < 10; ++i) Ns[i] = 0.0;
+#pragma unroll
+                        for (int c = 0; c < CT; ++c) {
+                            if (EXACT || c < C) {
+                                const T x = s.o[3 * c], y = s.o[3 * c + 1], w = s.o[3 * c + 2];
+                                accum_camera<1>(Ns, cams_here[c].P, (double)x, (double)y, ((kept >> c) & 1u) ? (double)w : 0.0);
+                            }
+                        }
                     }
                     double q[3];
                     smallest_eigvec(Ns, q);
                     if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
-                    // the projection matrices are scalar loads at their point of use: an opaque copy of the pointer keeps the
-                    // compiler from hoisting 192 SGPRs' worth of them out of the loops
-                    cam_cptr cams_here = cams;
                     asm volatile("" : "+s"(cams_here));
                     const double e = mean_error<T, false, CT>(cams_here, C, sobs, kept, q);
                     // argmin per unit on (error, rank), np.nanargmin (triangulation.py:500-503): the bits of a non-negative
@@ -314,7 +347,14 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                     wsync();
                     if (first) atomicMin(&s.rank, r);
                     wsync();
-                    if (first && s.rank == r) { s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2]; s.S = S; }
+                    __builtin_amdgcn_s_waitcnt(0);                         // (an earlier pass's points have been written)
+                    if (first && s.rank == r) {
+                        // the unit's best so far: its point goes straight over what the tile stored (the owner puts NaN there
+                        // again should the unit fail in the end); stores of one wave to one address arrive in program order
+                        s.S = S;
+                        double *Qu = a.Q + (a.block0 * K + (int64_t)s.unit) * 3;
+                        Qu[0] = q[0]; Qu[1] = q[1]; Qu[2] = q[2];
+                    }
                     st_evals += n; ++st_passes;
                     // what is left of the list moves to its head (at most 127 entries)
                     const uint32_t rem = nSurv - n;
@@ -505,14 +545,13 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             }
 
             // ---- results of the searched units (triangulation.py:588-604), patched over what their tile stored ------------
+            __builtin_amdgcn_s_waitcnt(0);
             if (own) {
                 const double e = __longlong_as_double((long long)mine.ebits);
                 const uint32_t bS = mine.S;
                 const bool ok = e <= thr;
                 const int64_t gu = a.block0 * K + (int64_t)mine.unit;
-                a.Q[gu * 3 + 0] = ok ? mine.q[0] : d_nan();
-                a.Q[gu * 3 + 1] = ok ? mine.q[1] : d_nan();
-                a.Q[gu * 3 + 2] = ok ? mine.q[2] : d_nan();
+                if (!ok) { a.Q[gu * 3 + 0] = d_nan(); a.Q[gu * 3 + 1] = d_nan(); a.Q[gu * 3 + 2] = d_nan(); }
                 a.err[gu] = ok ? (float)e : __builtin_nanf("");
                 a.mask[gu] = m_nan | bS;
                 a.n_excl[gu] = (uint8_t)(m_V + __popc(bS & m_valid));          // :436 counts NaN or zero
@@ -522,9 +561,12 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             cnt = min(NSLOT, n_over - over_done);
             wsync();
             if (lane < cnt) {
-                const uint32_t o = sOver[over_done + lane];
+                // (opaque copies: nothing of this rare path is to be prepared ahead and held in registers through the search)
+                uint32_t Kq = (uint32_t)K, ln = (uint32_t)lane;
+                asm volatile("" : "+s"(Kq), "+v"(ln));
+                const uint32_t o = sOver[(uint32_t)over_done + ln];
                 const uint32_t u = ((tile0 + (o >> 6) * tstride) << 6) + (o & 63u);
-                const uint32_t b = u / (uint32_t)K, k = u - b * (uint32_t)K;
+                const uint32_t b = u / Kq, k = u - b * Kq;
                 RegObs<T, CT> ob;
                 ob.lik_thr = a.lik_thr;
                 load_obs<T, CT, EXACT>(a, C, b, k, ob);
@@ -535,6 +577,10 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
                 classify_and_accumulate<T, CT>(cams, C, ob, N2, nan2, zero2);
                 double q2[3];
                 smallest_eigvec(N2, q2);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (((nan2 | zero2) >> c) & 1u) { ob.x[c] = (T)0; ob.y[c] = (T)0; ob.w[c] = (T)0; }
+                }
                 fill_slot(slots[lane], N2, q2, nan2, zero2, u, ob);
             }
             over_done += cnt;
@@ -653,7 +699,7 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         if (need) {
             const int ord = n_used + n_over + __popcll(hard & lt);
             if (ord < NSLOT) fill_slot(slots[ord], N, q, nanmask, zeromask, (tile << 6) + (uint32_t)lane, obs);
-            else sOver[ord - NSLOT] = (uint8_t)(t * 64 + lane);
+            else sOver[ord - NSLOT] = (uint16_t)(t * 64 + lane);
         }
         {
             const int tot = n_used + n_over + __popcll(hard);
@@ -766,24 +812,26 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         if (hard != 0ull) {
             const int ord = n_used + n_over + __popcll(hard & lt);
             const bool slotted = need && ord < NSLOT;
-            if (need && !slotted) sOver[ord - NSLOT] = (uint8_t)(t * 64 + lane);
+            if (need && !slotted) sOver[ord - NSLOT] = (uint16_t)(t * 64 + lane);
             slot_t &s = slots[slotted ? ord : 0];
-            if (slotted) {
-#pragma unroll
-                for (int i = 0; i < 10; ++i) s.N[i] = N[i];
-                s.q[0] = q[0]; s.q[1] = q[1]; s.q[2] = q[2];
-                s.nan = nanmask; s.zero = zeromask; s.unit = (tile << 6) + (uint32_t)lane;
-            }
+            if (slotted) fill_head(s, N, q, nanmask, zeromask, (tile << 6) + (uint32_t)lane);
             // another read, by the lanes that park a unit only (they need the likelihoods again)
             if (slotted) {
                 asm volatile("" : "+v"(ub2));
                 load_half<T, EXACT>(a, C, ub2, uk, 0, h0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { s.o[3 * i] = h0.x[i]; s.o[3 * i + 1] = h0.y[i]; s.o[3 * i + 2] = h0.w[i]; }
+                for (int i = 0; i < 8; ++i) {
+                    const bool okc = (valid >> i) & 1u;
+                    s.o[3 * i] = okc ? h0.x[i] : (T)0; s.o[3 * i + 1] = okc ? h0.y[i] : (T)0; s.o[3 * i + 2] = okc ? h0.w[i] : (T)0;
+                }
                 asm volatile("" : "+v"(ub2));
                 load_half<T, EXACT>(a, C, ub2, uk, 8, h0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { s.o[24 + 3 * i] = h0.x[i]; s.o[24 + 3 * i + 1] = h0.y[i]; s.o[24 + 3 * i + 2] = h0.w[i]; }
+                for (int i = 0; i < 8; ++i) {
+                    const bool okc = (valid >> (8 + i)) & 1u;
+                    s.o[24 + 3 * i] = okc ? h0.x[i] : (T)0; s.o[24 + 3 * i + 1] = okc ? h0.y[i] : (T)0;
+                    s.o[24 + 3 * i + 2] = okc ? h0.w[i] : (T)0;
+                }
             }
             const int tot = n_used + n_over + __popcll(hard);
             n_over = max(0, tot - NSLOT);
@@ -793,9 +841,10 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         store_tile(tile);
     };
 
-    RegObs<T, CT> obs0, obs1, obs2, obs3;
+    RegObs<T, CT> obs0, obs1, obs2, obs3, obs4, obs5;
     obs0.lik_thr = a.lik_thr; obs1.lik_thr = a.lik_thr; obs2.lik_thr = a.lik_thr; obs3.lik_thr = a.lik_thr;
-    bool act0, act1 = false, act2 = false, act3 = false;
+    obs4.lik_thr = a.lik_thr; obs5.lik_thr = a.lik_thr;
+    bool act0, act1 = false, act2 = false, act3 = false, act4 = false, act5 = false;
     if constexpr (CT <= 8) {
         const uint32_t u0 = unit_of(tile0, act0);
         load_obs<T, CT, EXACT>(a, C, u0 / (uint32_t)K, u0 % (uint32_t)K, obs0);
@@ -805,6 +854,8 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
     const bool two = my_tiles > 1 && tile0 + tstride < n_tiles;
     const bool three = TPW > 2 && my_tiles > 2 && tile0 + 2 * tstride < n_tiles;
     const bool four = TPW > 3 && my_tiles > 3 && tile0 + 3 * tstride < n_tiles;
+    const bool five = TPW > 4 && my_tiles > 4 && tile0 + 4 * tstride < n_tiles;
+    const bool six = TPW > 5 && my_tiles > 5 && tile0 + 5 * tstride < n_tiles;
     auto request = [&](const bool wanted, const int t, bool &act, RegObs<T, CT> &obs, double dep) {
         if (wanted) {
             uint32_t u = unit_of(tile0 + (uint32_t)t * tstride, act);
@@ -816,6 +867,7 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         level0_wide(0);
         if constexpr (TPW > 1) { if (two) level0_wide(1); }
         if constexpr (TPW > 2) { if (three) level0_wide(2); }
+        if constexpr (TPW > 3) { if (four) level0_wide(3); }
     } else {
     level0(0, act0, obs0, [&](double dep) { if constexpr (TPW > 1) request(two, 1, act1, obs1, dep); });
     if constexpr (TPW > 1) {
@@ -825,7 +877,13 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         if (three) level0(2, act2, obs2, [&](double dep) { if constexpr (TPW > 3) request(four, 3, act3, obs3, dep); });
     }
     if constexpr (TPW > 3) {
-        if (four) level0(3, act3, obs3, [](double) {});
+        if (four) level0(3, act3, obs3, [&](double dep) { if constexpr (TPW > 4) request(five, 4, act4, obs4, dep); });
+    }
+    if constexpr (TPW > 4) {
+        if (five) level0(4, act4, obs4, [&](double dep) { if constexpr (TPW > 5) request(six, 5, act5, obs5, dep); });
+    }
+    if constexpr (TPW > 5) {
+        if (six) level0(5, act5, obs5, [](double) {});
     }
     }
 
@@ -876,8 +934,10 @@ bool p2s_tri_pool_supports(int C, int dtype, int undistort, int lr_swap) {
 hipError_t p2s_launch_tri_pool(const P2sTriArgs &a, int dtype, int singles_pct, int tiles_per_wave, hipStream_t s) {
     (void)dtype;
     if (a.C > 8) return launch_pool<float, 16, 20, 2>(a, singles_pct, s);
-    if (a.C <= 4) return launch_pool<float, 4, 32, 3>(a, singles_pct, s);
+    if (a.C <= 4) return launch_pool<float, 4, 48, 5>(a, singles_pct, s);
     if (tiles_per_wave == 2) return launch_pool<float, 8, 32, 2>(a, singles_pct, s);
-    if (tiles_per_wave == 4) return launch_pool<float, 8, P2S_POOL_SLOTS4, 4>(a, singles_pct, s);
-    return launch_pool<float, 8, 32, 3>(a, singles_pct, s);
+    if (tiles_per_wave == 3) return launch_pool<float, 8, 32, 3>(a, singles_pct, s);
+    if (tiles_per_wave == 4) return launch_pool<float, 8, 40, 4>(a, singles_pct, s);
+    if (tiles_per_wave == 6) return launch_pool<float, 8, 52, 6>(a, singles_pct, s);
+    return launch_pool<float, 8, 48, 5>(a, singles_pct, s);
 }
