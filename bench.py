@@ -6,8 +6,8 @@
 A "step" is one pass of the hot path (p2s_triangulate_device: stage + undistort/mask + weighted
 DLT + camera-subset search) over one synthetic batch that is already resident in HBM.  With
 N > 1 ranks (torchrun, one per GPU) every rank holds its own frame shard of the same size (weak
-scaling) and a step ends with the single all-gather of the packed per-unit results over
-RCCL/xGMI that BASELINE.json's north_star names.  Rank 0 prints ONE JSON line.
+scaling) and a step ends with the all-gather of the per-unit points (24 B per unit; and of the
+per-frame means, 16 B per frame and person) over RCCL/xGMI that BASELINE.json's north_star names.  Rank 0 prints ONE JSON line.
 
 The roofline leg times the kernel alone with HIP events on the launch stream; the cpu_baseline
 leg times the CPU oracle (oracle/, a loop-faithful port of the reference) on a bounded sample.
@@ -562,12 +562,18 @@ def main():
                                                     distort=cfg['undistort'], p_lr_swap=0.02 if cfg['lr_swap'] else 0.0,
                                                     swap_idx=swap_list, **gen) for i in range(n_buf)]
     d_swap = torch.from_numpy(swap).to(dev)
-    # packed result buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8], 16-byte aligned sections -> one all-gather
+    # packed result buffer [Q f64 x3 | err f32 | mask u32 | n_excl u8], 16-byte aligned sections.  What travels is what
+    # parallel.gather_trajectory sends: the points' section (24 B per unit) and, in a second small all-gather, the
+    # per-(frame, person) mean error and mean exclusion count (16 B per K units; the product computes them on the host
+    # from the rank's own tables, which like every result at N = 1 stay where the kernel wrote them during the bench)
     from pose2sim_amd import parallel
     off_e, off_m, off_n, nbytes = parallel.section_offsets(n_units)
+    q_bytes, mean_bytes = n_units * 24, n_blocks * 16
     # two result buffers: the all-gather of step i runs on RCCL's stream while step i+1 computes
     d_outs = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2 if multi else 1)]
-    d_alls = [torch.empty(nbytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else []
+    d_alls = [torch.empty(q_bytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else []
+    d_means = [torch.zeros(mean_bytes, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else []
+    d_mean_alls = [torch.empty(mean_bytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if multi else []
     d_out = d_outs[0]
     base = d_out.data_ptr()
     pending = [None, None]
@@ -578,15 +584,17 @@ def main():
         x = d_xyls[counter[0] % n_buf]
         counter[0] += 1
         if multi and pending[i] is not None:
-            pending[i].wait()                      # buffer i is free again (its all-gather has finished)
+            for w in pending[i]:
+                w.wait()                           # buffer i is free again (its all-gathers have finished)
         b = d_outs[i].data_ptr()
         eng.triangulate_device(n_blocks, K, P2S_F32, x, d_swap, prm, b, b + off_e, b + off_n, b + off_m)
         if multi:
-            pending[i] = dist.all_gather_into_tensor(d_alls[i], d_outs[i], async_op=True)
+            pending[i] = (dist.all_gather_into_tensor(d_alls[i], d_outs[i][:q_bytes], async_op=True),
+                          dist.all_gather_into_tensor(d_mean_alls[i], d_means[i], async_op=True))
 
     def drain():
-        for w in pending:
-            if w is not None:
+        for ws in pending:
+            for w in (ws or ()):
                 w.wait()
         pending[0] = pending[1] = None
 
@@ -673,7 +681,7 @@ def main():
                                   'evaluation_passes_per_step': stats['passes'],
                                   'screened_subsets_per_step': stats['screened_subsets'], 'screen_passes_per_step': stats['screen_passes'],
                                   'capped_units_per_step': stats['capped_units']},
-                       'parallelism': f'frame shards x{world}' + (' + 1 all-gather/step (async, overlapped with the next step)' if multi else '')},
+                       'parallelism': f'frame shards x{world}' + (' + all-gather of the points (24 B per unit) per step (async, overlapped with the next step)' if multi else '')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'fp64_frac': flops / (k_ms * 1e-3) / FP64_PEAK, 'fp64_tflops': flops / (k_ms * 1e-3) / 1e12,
@@ -689,9 +697,10 @@ def main():
                          'kernel_ms': k_ms, 'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
         }
         if multi:
-            # the split a reader needs to judge the scaling: the all-gather moves 33 B per unit into every rank over
-            # xGMI (one link per peer), the kernels alone run at kernel_ms per step on every rank
-            out['collective'] = {'kind': 'all_gather_into_tensor (RCCL), async, double-buffered', 'bytes_per_rank_per_step': int(nbytes),
+            # the split a reader needs to judge the scaling: the all-gather moves 24 B per unit (the points) and 16 B per
+            # (frame, person) into every rank over xGMI (one link per peer), the kernels alone run at kernel_ms per step
+            out['collective'] = {'kind': 'all_gather_into_tensor (RCCL) x2 (points, per-frame means), async, double-buffered',
+                                 'bytes_per_rank_per_step': int(q_bytes + mean_bytes),
                                  'value_kernels_only': n_units * world / (k_ms * 1e-3)}
         out.update(cpu if cpu else {'cpu_baseline': None})
         print(json.dumps(out), flush=True)

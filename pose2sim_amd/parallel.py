@@ -1,10 +1,11 @@
 """Frame sharding across the GPUs of one node.
 
 Every (frame, person, keypoint) unit is independent, so rank r of G takes the contiguous frame
-block [r*F/G, (r+1)*F/G); the only exchange step is ONE all-gather of the packed per-unit results
-(32 + 1 bytes per unit) -- RCCL over xGMI when the process group is 'nccl', gloo on CPU in tests.
-The sequential post-processing (tracking, interpolation, .trc) then runs on every rank's copy and
-only rank 0 writes files.
+block [r*F/G, (r+1)*F/G); the only large exchange is ONE all-gather of the points (24 bytes per unit,
+gather_trajectory) -- RCCL over xGMI when the process group is 'nccl', gloo on CPU in tests -- beside three small
+ones: the per-frame means that pick the kept frames, rank 0's verdict on them, and the column sums of the report.
+The sequential post-processing (tracking, interpolation, .trc) runs on rank 0, which writes the files.
+(gather_results, the all-gather of all 33 bytes per unit, remains for callers that want every table on every rank.)
 """
 import os
 
@@ -156,6 +157,114 @@ def gather_results(local, F, Pn, K, host_copy_on=None):
     nf = np.concatenate([o[2] for o in outs]).reshape(F, Pn, K)
     mf = np.concatenate([o[3] for o in outs]).reshape(F, Pn, K)
     return Qf, ef, nf, mf
+
+
+class LocalTables:
+    """What a rank keeps of its own frame block after the trajectory exchange: err f32 / n_excl u8 / mask u32, each
+    [frames][Pn][K], and the first frame of the block."""
+
+    def __init__(self, lo, err, n_excl, mask):
+        self.lo, self.err, self.n_excl, self.mask = lo, err, n_excl, mask
+
+
+def gather_trajectory(local, F, Pn, K, skipna, host_copy_on=None):
+    """The path's exchange in its lean form: what the sequential steps need of every frame is the points (24 bytes per
+    unit) and, per (frame, person), the mean error and mean number of excluded cameras that decide which frames a
+    trial keeps (triangulation.py:897-901) -- 16 bytes per K units.  The per-unit errors, exclusion counts and camera
+    masks (9 bytes per unit) stay on the rank that computed them; the report's column means over the kept frames are
+    summed per rank and reduced (reduce_report_sums).
+
+    local: (Q, err, n_excl, mask) host arrays of this rank's block or a PackedDeviceResults.  Returns
+    (Q [F][Pn][K][3] -- None on the ranks other than host_copy_on --, row_means [F][Pn][2] on every rank, LocalTables).
+    """
+    from . import postproc
+    rank, world = dist_info()
+    import torch
+    import torch.distributed as dist
+    nb_max = largest_shard(F, world) * Pn
+    lo, hi = shard_bounds(F, rank, world)
+    nb = (hi - lo) * Pn
+    if isinstance(local, PackedDeviceResults):
+        assert local.n_blocks_padded == nb_max and local.K == K and local.n_blocks == nb
+        off_e, off_m, off_n, total = section_offsets(nb_max * K)
+        t_q = local.buf[:nb_max * K * 24]                                   # the points' section, as the kernels wrote it
+        tail = local.buf[off_e:total].cpu().numpy()                         # 9 of the 33 bytes per unit: to this rank's host only
+        n = nb_max * K
+        err = tail[:n * 4].view(np.float32).reshape(nb_max, K)[:nb]
+        mask = tail[off_m - off_e:off_m - off_e + n * 4].view(np.uint32).reshape(nb_max, K)[:nb]
+        nex = tail[off_n - off_e:off_n - off_e + n].reshape(nb_max, K)[:nb]
+    else:
+        Q, err, nex, mask = local
+        err = np.asarray(err, dtype=np.float32).reshape(nb, K)
+        nex = np.asarray(nex, dtype=np.uint8).reshape(nb, K)
+        mask = np.asarray(mask, dtype=np.uint32).reshape(nb, K)
+        q = _pad(np.ascontiguousarray(Q, dtype=np.float64).reshape(nb, K * 3), nb_max)
+        t_q = torch.from_numpy(q.view(np.uint8).reshape(-1)).to(collective_device())
+    means = np.full((nb_max, 2), np.nan)
+    if nb:
+        means[:nb, 0] = postproc.frame_means(err.astype(np.float64), skipna=skipna)
+        means[:nb, 1] = postproc.frame_means(nex.astype(np.float64))
+    t_m = torch.from_numpy(means.reshape(-1)).to(t_q.device)
+    t_q_all = torch.empty(world * t_q.numel(), dtype=torch.uint8, device=t_q.device)
+    t_m_all = torch.empty(world * t_m.numel(), dtype=torch.float64, device=t_q.device)
+    dist.all_gather_into_tensor(t_q_all, t_q)                               # the one large collective of the path
+    dist.all_gather_into_tensor(t_m_all, t_m)
+    m_all = t_m_all.cpu().numpy().reshape(world, nb_max, 2)
+    sizes = [(shard_bounds(F, r, world)[1] - shard_bounds(F, r, world)[0]) * Pn for r in range(world)]
+    row_means = np.concatenate([m_all[r, :sizes[r]] for r in range(world)]).reshape(F, Pn, 2)
+    tables = LocalTables(lo, err.reshape(hi - lo, Pn, K), nex.reshape(hi - lo, Pn, K), mask.reshape(hi - lo, Pn, K))
+    if host_copy_on is not None and rank != host_copy_on:
+        return None, row_means, tables
+    q_all = t_q_all.cpu().numpy().reshape(world, nb_max, K * 24)
+    Qf = np.concatenate([q_all[r, :sizes[r]] for r in range(world)]).reshape(-1).view(np.float64).reshape(F, Pn, K, 3)
+    return Qf, row_means, tables
+
+
+def broadcast_ints(values, n, src=0):
+    """An int64 vector of n entries from rank src to every rank (the sections kept and the person order per frame)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(n, dtype=torch.int64, device=collective_device())
+    if dist.get_rank() == src:
+        t.copy_(torch.from_numpy(np.ascontiguousarray(values, dtype=np.int64).reshape(-1)))
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def reduce_report_sums(tables, ids, sections, n_cams):
+    """Column sums of the report (triangulation.py:312-360, 934-943) over the kept frames of every person, from the
+    rank's own tables and summed over the ranks: per person and keypoint the sum and count of the errors that are
+    numbers and the sum of the exclusion counts, per person the number of frames and, per camera, of units that
+    excluded it.  ids [F][Pn]: the detection that person slot n takes in frame f (-1: none, whose row reads error NaN,
+    every camera excluded); sections [Pn][2]: first and one past the last kept frame.  Returns a dict of arrays."""
+    import torch
+    import torch.distributed as dist
+    nF, Pn, K = tables.err.shape
+    allmask = np.uint32((1 << n_cams) - 1) if n_cams < 32 else np.uint32(0xFFFFFFFF)
+    out = np.zeros((Pn, 3 * K + 1 + n_cams))
+    for n in range(Pn):
+        a, b = max(int(sections[n][0]), tables.lo), min(int(sections[n][1]), tables.lo + nF)
+        if b <= a:
+            continue
+        rows = np.arange(a - tables.lo, b - tables.lo)
+        d = ids[a:b, n]
+        took = d >= 0
+        dd = np.where(took, d, 0)
+        e = np.where(took[:, None], tables.err[rows, dd].astype(np.float64), np.nan)
+        x = np.where(took[:, None], tables.n_excl[rows, dd].astype(np.float64), float(n_cams))
+        m = np.where(took[:, None], tables.mask[rows, dd], allmask)
+        ok = ~np.isnan(e)
+        out[n, :K] = np.where(ok, e, 0.0).sum(axis=0)
+        out[n, K:2 * K] = ok.sum(axis=0)
+        out[n, 2 * K:3 * K] = x.sum(axis=0)
+        out[n, 3 * K] = b - a
+        flat = m.reshape(-1)
+        out[n, 3 * K + 1:] = [np.count_nonzero((flat >> np.uint32(c)) & np.uint32(1)) for c in range(n_cams)]
+    t = torch.from_numpy(out).to(collective_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    out = t.cpu().numpy()
+    return {'err_sum': out[:, :K], 'err_count': out[:, K:2 * K], 'excl_sum': out[:, 2 * K:3 * K], 'frames': out[:, 3 * K],
+            'cam_count': out[:, 3 * K + 1:]}
 
 
 def agree_ok(error=None):

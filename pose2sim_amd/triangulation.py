@@ -58,41 +58,36 @@ def select_pose_inputs(project_dir):
     return used, json_dirs_names, json_files_names
 
 
-def track_persons(Q, err, nex, ids_mask, f_range, multi_person, max_distance_m, n_cams):
-    """triangulation.py:823-874 on the kernel's outputs, frame by frame.
+def track_persons(Q, f_range, multi_person, max_distance_m):
+    """triangulation.py:823-874 on the kernel's points, frame by frame: which detection every person slot takes.
 
-    Q [F][P][K][3], err [F][P][K], nex [F][P][K], ids_mask [F][P][K] (bit c = camera c excluded).
-    Returns the per-frame, per-person rows the reference appends to Q_tot / error_tot /
-    nb_cams_excluded_tot / id_excluded_cams_tot (persons 0..P-1 only, :870-874).
-    """
+    Q [F][P][K][3].  Returns (Q_rows [F][P][K][3], ids [F][P]): the points in tracked order and, per frame and slot, the
+    detection it took (-1: none; the reference then records error NaN and every camera excluded, :855-864).  Persons
+    0..P-1 only (:870-874)."""
     F, P, K, _ = Q.shape
+    ids = np.tile(np.arange(P), (F, 1))
     if not multi_person:
-        return Q, err.astype(np.float64), nex.astype(np.float64), ids_mask
-    allmask = np.uint32((1 << n_cams) - 1) if n_cams < 32 else np.uint32(0xFFFFFFFF)
+        return Q, ids
     Q_out = np.empty((F, P, K, 3))
-    e_out = np.empty((F, P, K))
-    n_out = np.empty((F, P, K))
-    m_out = np.empty((F, P, K), dtype=np.uint32)
     Q_cur = np.full((P, K, 3), np.nan)
     Q_old = np.full((P, K, 3), np.nan)
     for fi, f in enumerate(range(*f_range)):
         nan_mask = np.isnan(Q_cur)
         Q_old = np.where(nan_mask, Q_old, Q_cur)                      # :824-825
         Q_cur = Q[fi]
-        e_f, n_f, m_f = err[fi].astype(np.float64), nex[fi].astype(np.float64), ids_mask[fi]
         if f != 0:                                                    # :850 absolute frame number (quirk Q7)
             Q_old, Q_cur, sorted_ids = postproc.sort_people_sports2d(Q_old, np.array(Q_cur), max_dist=max_distance_m)
-            e_s = np.full((P, K), np.nan)
-            n_s = np.full((P, K), float(n_cams))
-            m_s = np.full((P, K), allmask, dtype=np.uint32)
-            for n in range(P):                                        # :855-864
-                d = int(sorted_ids[n])
-                if d >= 0:
-                    e_s[n], n_s[n], m_s[n] = e_f[d], n_f[d], m_f[d]
-            e_f, n_f, m_f = e_s, n_s, m_s
+            ids[fi] = [int(sorted_ids[n]) for n in range(P)]
         Q_out[fi] = Q_cur[:P]
-        e_out[fi], n_out[fi], m_out[fi] = e_f, n_f, m_f
-    return Q_out, e_out, n_out, m_out
+    return Q_out, ids
+
+
+def in_tracked_order(table, ids, empty):
+    """table [F][P][...] of per-detection values -> the rows of the person slots: slot n of frame f reads detection
+    ids[f][n], `empty` where it took none."""
+    took = ids >= 0
+    rows = np.take_along_axis(table, np.where(took, ids, 0).reshape(ids.shape + (1,) * (table.ndim - 2)), axis=1)
+    return np.where(took.reshape(ids.shape + (1,) * (table.ndim - 2)), rows, empty)
 
 
 class PersonTrial:
@@ -109,18 +104,16 @@ class PersonTrial:
         self.interpolated, self.not_interpolated = [], []
 
 
-def finish_person(n, coords, err, n_excl, masks, frames, settings, config_dict, keypoints_names, n_cams, write):
-    """triangulation.py:888-953 for one person, on arrays: coords [F][3 K], err / n_excl [F][K] float, masks [F][K] u32,
-    frames [F] absolute frame numbers.  Interpolates the short gaps, keeps the section(s) of frames with a mean error,
-    fills the long gaps, writes the .trc file (rank 0) and collects the report's figures."""
-    K = len(keypoints_names)
+def finish_person(n, coords, err_frame, excl_frame, frames, settings, config_dict, keypoints_names, write):
+    """triangulation.py:888-953 for one person, on arrays: coords [F][3 K], err_frame / excl_frame [F] (the frame's mean
+    error and mean number of excluded cameras), frames [F] absolute frame numbers.  Interpolates the short gaps, keeps
+    the section(s) of frames with a mean error, fills the long gaps and writes the .trc file (rank 0); the report's
+    per-keypoint figures are added by table_figures or summed_figures."""
     if settings['interpolation'] != 'none':
         try:
             coords = postproc.interpolate_gaps(coords, frames, settings['max_gap'], settings['interpolation'])
         except Exception:
             logging.warning(f'Interpolation was not possible for person {n}. This means that not enough points are available, which is often due to a bad calibration.')
-    err_frame = postproc.frame_means(err, skipna=not settings['remove_incomplete_frames'])       # :897
-    excl_frame = postproc.frame_means(n_excl)
     start, end = postproc.indices_of_first_last_non_nan_chunks(err_frame, min_chunk_size=settings['min_chunk_size'],
                                                                chunk_choice_method=settings['sections_to_keep'])
     person = PersonTrial(start, end)
@@ -139,16 +132,32 @@ def finish_person(n, coords, err, n_excl, masks, frames, settings, config_dict, 
                                         frames[start:end], coords, keypoints_names, trc.resolve_frame_rate(config_dict))
         if settings['make_c3d']:
             logging.warning('make_c3d: the c3d package is not available in this build; only the .trc file was written.')
-    person.err_per_kpt = postproc.column_means(err[start:end])
-    person.excl_per_kpt = postproc.column_means(n_excl[start:end])
     person.err_mean = postproc.column_means(err_frame[start:end, None])[0]
     person.excl_mean = postproc.column_means(excl_frame[start:end, None])[0]
-    person.cam_fractions = postproc.camera_exclusion_fractions(masks[start:end], n_cams)
     if settings['show_interp_indices']:
         person.interpolated, person.not_interpolated = done, left
     else:
         person.interpolated, person.not_interpolated = None, []
     return person
+
+
+def table_figures(person, err, n_excl, masks, n_cams):
+    """The report's per-keypoint means and per-camera shares over the person's kept frames from the whole tables
+    (one process): err / n_excl [F][K] float, masks [F][K] u32."""
+    if person.kept:
+        person.err_per_kpt = postproc.column_means(err[person.start:person.end])
+        person.excl_per_kpt = postproc.column_means(n_excl[person.start:person.end])
+        person.cam_fractions = postproc.camera_exclusion_fractions(masks[person.start:person.end], n_cams)
+
+
+def summed_figures(person, sums, n):
+    """The same figures from the column sums the ranks reduced (parallel.reduce_report_sums)."""
+    if person.kept:
+        with np.errstate(invalid='ignore', divide='ignore'):
+            person.err_per_kpt = np.where(sums['err_count'][n] > 0, sums['err_sum'][n] / sums['err_count'][n], np.nan)
+            person.excl_per_kpt = sums['excl_sum'][n] / sums['frames'][n]
+            total = sums['frames'][n] * len(person.err_per_kpt)
+            person.cam_fractions = {c: int(v) / total for c, v in enumerate(sums['cam_count'][n])}
 
 
 def triangulate_all(config_dict):
@@ -231,21 +240,52 @@ def triangulate_all(config_dict):
             raise
         failure = exc
     parallel.agree_ok(failure)
-    gathered = parallel.gather_results(local, n_frames, nb_persons, keypoints_nb, host_copy_on=0 if world > 1 else None)
-    if gathered is None:
-        return []                                          # tracking, interpolation and the .trc files are rank 0's
-    Qk, ek, nk, mk = gathered
-
-    Q_rows, e_rows, n_rows, m_rows = track_persons(Qk, ek, nk, mk, f_range, multi_person, max_distance_m, n_cams)
     frames = np.arange(*f_range)
     settings = {'interpolation': interpolation_kind, 'max_gap': interp_gap_smaller_than, 'remove_incomplete_frames': remove_incomplete_frames,
                 'sections_to_keep': sections_to_keep, 'min_chunk_size': min_chunk_size, 'fill_large_gaps_with': fill_large_gaps_with,
                 'show_interp_indices': show_interp_indices, 'make_c3d': make_c3d}
-    persons = [finish_person(n, Q_rows[:, n].reshape(len(frames), keypoints_nb * 3), e_rows[:, n].astype(np.float64),
-                             n_rows[:, n].astype(np.float64), m_rows[:, n], frames, settings, config_dict, keypoints_names, n_cams,
-                             write=(rank == 0)) for n in range(nb_persons)]
-    if all(p.end == p.start for p in persons):                                 # :955-956
-        raise Exception('No persons have been triangulated. Please check your calibration and your synchronization, or the triangulation parameters in Config.toml.')
+    skipna = not remove_incomplete_frames                                      # :897
+    allmask = np.uint32((1 << n_cams) - 1) if n_cams < 32 else np.uint32(0xFFFFFFFF)
+
+    def sequential_steps(Qk, err_frames, excl_frames):
+        """Tracking, then per person interpolation, kept section, gap filling and the file (rank 0)."""
+        Q_rows, ids = track_persons(Qk, f_range, multi_person, max_distance_m)
+        e_fr = in_tracked_order(err_frames, ids, np.nan)
+        x_fr = in_tracked_order(excl_frames, ids, float(n_cams))
+        people = [finish_person(n, Q_rows[:, n].reshape(len(frames), keypoints_nb * 3), e_fr[:, n], x_fr[:, n], frames, settings,
+                                config_dict, keypoints_names, write=(rank == 0)) for n in range(nb_persons)]
+        if all(p.end == p.start for p in people):                              # :955-956
+            raise Exception('No persons have been triangulated. Please check your calibration and your synchronization, or the triangulation parameters in Config.toml.')
+        return people, ids
+
+    if world == 1:
+        Qk, ek, nk, mk = local
+        ek, nk = np.asarray(ek, dtype=np.float64), np.asarray(nk, dtype=np.float64)
+        flat = lambda t: t.reshape(-1, t.shape[-1])                            # noqa: E731
+        persons, ids = sequential_steps(Qk, postproc.frame_means(flat(ek), skipna=skipna).reshape(ek.shape[:2]),
+                                        postproc.frame_means(flat(nk)).reshape(nk.shape[:2]))
+        e_rows, n_rows, m_rows = in_tracked_order(ek, ids, np.nan), in_tracked_order(nk, ids, float(n_cams)), in_tracked_order(mk, ids, allmask)
+        for n, person in enumerate(persons):
+            table_figures(person, e_rows[:, n], n_rows[:, n], m_rows[:, n], n_cams)
+    else:
+        # the points and the per-frame means travel; the per-unit tables stay where they were computed and only their
+        # column sums over the kept frames are exchanged once rank 0 has settled which frames those are
+        Qk, row_means, tables = parallel.gather_trajectory(local, n_frames, nb_persons, keypoints_nb, skipna, host_copy_on=0)
+        persons, verdict, failure = None, np.zeros(nb_persons * 2 + n_frames * nb_persons, dtype=np.int64), None
+        if rank == 0:
+            try:
+                persons, ids = sequential_steps(Qk, row_means[:, :, 0], row_means[:, :, 1])
+                verdict = np.concatenate([np.array([[p.start, p.end] for p in persons]).reshape(-1), ids.reshape(-1)])
+            except Exception as exc:                       # noqa: BLE001 -- the other ranks wait in the broadcast below
+                failure = exc
+        parallel.agree_ok(failure)
+        verdict = parallel.broadcast_ints(verdict, nb_persons * 2 + n_frames * nb_persons)
+        sums = parallel.reduce_report_sums(tables, verdict[nb_persons * 2:].reshape(n_frames, nb_persons),
+                                           verdict[:nb_persons * 2].reshape(nb_persons, 2), n_cams)
+        if rank != 0:
+            return []                                      # the files and the report are rank 0's
+        for n, person in enumerate(persons):
+            summed_figures(person, sums, n)
     if rank == 0:
         recap_triangulate(config_dict, persons, keypoints_names, f_range, calib_file)
     return [p.trc_path for p in persons]

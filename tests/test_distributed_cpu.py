@@ -93,7 +93,10 @@ def _trial_worker(rank, world, port, root, trial, multi):
     triangulation._make_engine = lambda: OracleEngine()
     cfg = ec.base_config(trial, multi)
     cfg['project']['project_dir'] = trial
+    import logging
+    logging.basicConfig(filename=os.path.join(root, f'log{rank}.txt'), level=logging.INFO, format='%(message)s', force=True)
     paths = triangulation.triangulate_all(cfg)
+    logging.shutdown()
     with open(os.path.join(root, f'rank{rank}.txt'), 'w') as fh:
         fh.write(repr(parsed) + '\n' + repr([os.path.basename(p) for p in paths if p]))
     dist.destroy_process_group()
@@ -119,6 +122,12 @@ def test_two_ranks_read_only_their_frames_and_write_the_same_trc(tmp_path, multi
         if mode == 'single':
             cwd = os.getcwd()
             os.chdir(root)
+            import logging
+            handler = logging.FileHandler(os.path.join(root, 'log0.txt'))
+            handler.setFormatter(logging.Formatter('%(message)s'))
+            level = logging.getLogger().level
+            logging.getLogger().addHandler(handler)
+            logging.getLogger().setLevel(logging.INFO)
             try:
                 orig = triangulation._make_engine
                 triangulation._make_engine = lambda: OracleEngine()
@@ -126,11 +135,20 @@ def test_two_ranks_read_only_their_frames_and_write_the_same_trc(tmp_path, multi
             finally:
                 triangulation._make_engine = orig
                 os.chdir(cwd)
+                logging.getLogger().removeHandler(handler)
+                logging.getLogger().setLevel(level)
+                handler.close()
         else:
             mp.spawn(_trial_worker, args=(2, _free_port(), root, trial, multi), nprocs=2, join=True)
         d = os.path.join(trial, 'pose-3d')
         outs[mode] = {f: open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.endswith('.trc')}
     assert outs['single'] and outs['single'] == outs['two']
+    # the report (triangulation.py:255-360): rank 0 of the two prints what the single process prints -- its per-keypoint
+    # means come from column sums reduced over the ranks instead of the whole tables -- and rank 1 prints none of it
+    report = {mode: open(os.path.join(str(tmp_path / mode), 'log0.txt')).read().replace(str(tmp_path / mode), '') for mode in outs}
+    assert 'Mean reprojection error for' in report['single'] and 'excluded' in report['single']
+    assert report['single'] == report['two']
+    assert 'Mean reprojection error' not in open(os.path.join(str(tmp_path / 'two'), 'log1.txt')).read()
     r0 = open(os.path.join(str(tmp_path / 'two'), 'rank0.txt')).read().split('\n')
     r1 = open(os.path.join(str(tmp_path / 'two'), 'rank1.txt')).read().split('\n')
     assert r0[0] == repr([(0, 12)]) and r1[0] == repr([(12, 23)])          # each rank parsed only its own block
@@ -243,3 +261,67 @@ def test_a_failing_rank_makes_every_rank_raise(tmp_path):
     mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / 'agree1.txt').read().startswith('own: rank 1 cannot read')
     assert open(tmp_path / 'agree0.txt').read().startswith('other: another rank failed')
+
+
+def _sums_worker(rank, world, port, out_dir, F, Pn, K, C):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from pose2sim_amd import parallel
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    Q, err, nex, mask, ids, sections = _sums_case(F, Pn, K, C)
+    lo, hi = parallel.shard_bounds(F, rank, world)
+    Qf, means, tables = parallel.gather_trajectory((Q[lo:hi], err[lo:hi], nex[lo:hi], mask[lo:hi]), F, Pn, K, skipna=True, host_copy_on=0)
+    sums = parallel.reduce_report_sums(tables, ids, sections, C)
+    np.savez(os.path.join(out_dir, f'sums{rank}.npz'), means=means, has_q=Qf is not None, Q=Qf if Qf is not None else np.zeros(0), **sums)
+    dist.destroy_process_group()
+
+
+def _sums_case(F, Pn, K, C):
+    rng = np.random.default_rng(5)
+    Q = rng.normal(size=(F, Pn, K, 3))
+    Q[rng.random((F, Pn, K)) < 0.1] = np.nan
+    err = rng.uniform(0, 20, size=(F, Pn, K)).astype(np.float32)
+    err[np.isnan(Q[..., 0])] = np.nan
+    err[3] = np.nan                                                     # a frame without any error
+    nex = rng.integers(0, C, size=(F, Pn, K)).astype(np.uint8)
+    mask = rng.integers(0, 1 << C, size=(F, Pn, K)).astype(np.uint32)
+    ids = np.stack([rng.permutation(Pn) for _ in range(F)])
+    ids[rng.random((F, Pn)) < 0.15] = -1                                # slots that took no detection
+    sections = np.array([[2, F - 3], [0, F], [5, 5]][:Pn])
+    return Q, err, nex, mask, ids, sections
+
+
+def test_report_sums_match_the_whole_tables(tmp_path):
+    """gather_trajectory + reduce_report_sums under two gloo ranks against the one-process arithmetic on the whole
+    tables: the points reassembled bit for bit on rank 0 only, the per-frame means on every rank, and the column sums
+    over each person's kept frames in tracked order (empty slots: error NaN, every camera excluded)."""
+    from pose2sim_amd import postproc, triangulation
+    F, Pn, K, C = 29, 3, 7, 5
+    mp.spawn(_sums_worker, args=(2, _free_port(), str(tmp_path), F, Pn, K, C), nprocs=2, join=True)
+    Q, err, nex, mask, ids, sections = _sums_case(F, Pn, K, C)
+    z0, z1 = np.load(tmp_path / 'sums0.npz'), np.load(tmp_path / 'sums1.npz')
+    assert bool(z0['has_q']) and not bool(z1['has_q'])
+    assert np.array_equal(z0['Q'], Q, equal_nan=True)
+    want_means = np.stack([postproc.frame_means(err.reshape(-1, K).astype(np.float64)).reshape(F, Pn),
+                           postproc.frame_means(nex.reshape(-1, K).astype(np.float64)).reshape(F, Pn)], axis=-1)
+    for z in (z0, z1):
+        assert np.array_equal(z['means'], want_means, equal_nan=True)
+    e_rows = triangulation.in_tracked_order(err.astype(np.float64), ids, np.nan)
+    n_rows = triangulation.in_tracked_order(nex.astype(np.float64), ids, float(C))
+    m_rows = triangulation.in_tracked_order(mask, ids, np.uint32((1 << C) - 1))
+    for n in range(Pn):
+        a, b = sections[n]
+        for z in (z0, z1):
+            assert z['frames'][n] == b - a
+            if b > a:
+                cnt = z['err_count'][n]
+                assert np.array_equal(cnt, (~np.isnan(e_rows[a:b, n])).sum(axis=0))
+                np.testing.assert_allclose(z['err_sum'][n] / np.where(cnt > 0, cnt, np.nan), postproc.column_means(e_rows[a:b, n]), rtol=1e-13)
+                np.testing.assert_allclose(z['excl_sum'][n] / (b - a), postproc.column_means(n_rows[a:b, n]), rtol=1e-13)
+                frac = postproc.camera_exclusion_fractions(m_rows[a:b, n], C)
+                assert {c: int(v) / ((b - a) * K) for c, v in enumerate(z['cam_count'][n])} == frac
+            else:
+                assert not z['err_sum'][n].any() and not z['cam_count'][n].any()

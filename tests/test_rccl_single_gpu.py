@@ -42,6 +42,17 @@ SCRIPT = textwrap.dedent('''
     whole = parallel.gather_results(exact, F, Pn, K, host_copy_on=0)
     for a, b in zip(direct, whole):
         assert np.array_equal(np.asarray(a).reshape(np.asarray(b).shape), b, equal_nan=True)
+    # the product's exchange: the points' section of the device buffer is gathered as it is, the per-unit tables come to
+    # this rank's host only, the report's column sums are reduced
+    from pose2sim_amd import postproc
+    Qf, means, tables = parallel.gather_trajectory(exact, F, Pn, K, skipna=True, host_copy_on=0)
+    assert np.array_equal(Qf, direct[0], equal_nan=True)
+    assert np.array_equal(tables.err, direct[1], equal_nan=True) and np.array_equal(tables.n_excl, direct[2]) and np.array_equal(tables.mask, direct[3])
+    assert np.array_equal(means[:, :, 0], postproc.frame_means(direct[1].reshape(-1, K).astype(np.float64)).reshape(F, Pn), equal_nan=True)
+    ids = np.tile(np.arange(Pn), (F, 1))
+    sums = parallel.reduce_report_sums(tables, ids, np.array([[0, F]] * Pn), 5)
+    np.testing.assert_allclose(sums['err_sum'][1], np.nansum(direct[1][:, 1].astype(np.float64), axis=0), rtol=1e-13)
+    assert sums['frames'][0] == F
     # bench.py's form: packed device buffer, asynchronous all-gather into a second buffer
     n = 1 << 20
     src = torch.arange(n, dtype=torch.int64, device='cuda').to(torch.uint8)
