@@ -5,7 +5,7 @@ Phases are cut at landmark instructions (the tile's loads and stores, the recipr
 square roots of the reprojection passes).  usage: isa_phases.py file.s"""
 import re, sys, collections
 lines = open(sys.argv[1]).read().split('\n')
-key = 'p2s_tri_pool_kernelIfLi8ELi32ELb1ELi3E'
+key = 'p2s_tri_pool_kernelIfLi8ELi48ELb1ELi5E'
 start = next(i for i, l in enumerate(lines) if re.match(r'^_Z\w+:', l) and key in l)
 end = next(i for i in range(start, len(lines)) if 's_endpgm' in lines[i])
 body = lines[start:end]

@@ -218,6 +218,9 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
     const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const bool screen_on = a.screen != 0;
+    // likelihood test in the observations' own precision: for a float w, (double)w < t  <=>  w < (smallest float >= t)
+    T lik_t = (T)a.lik_thr;
+    if ((double)lik_t < a.lik_thr) lik_t = (T)nextafterf((float)lik_t, __builtin_huge_valf());
     for (int i = lane; i < C * 12; i += 64) {
         sPf[i] = (float)a.cams[i / 12].P[i % 12];
         if constexpr (KEEPN) sP[i] = a.cams[i / 12].P[i % 12];
@@ -641,10 +644,14 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const T x = cur.x[c], y = cur.y[c], w = cur.w[c];
-            const bool isn = (EXACT || c < C) && (!(w == w) || ((double)w < a.lik_thr));
+            const bool isn = (EXACT || c < C) && (!(w == w) || (w < lik_t));
             const bool isz = (EXACT || c < C) && (w == (T)0) && !isn;
             nanmask |= isn ? (1u << c) : 0u;
             zeromask |= isz ? (1u << c) : 0u;
+            // (the bits are set here: left to itself the compiler keeps the 16 comparison results in scalar register pairs,
+            // spills those to lanes of a vector register and assembles the masks after the eigen-solve: 18 instructions per
+            // camera instead of 9)
+            asm volatile("" : "+v"(nanmask), "+v"(zeromask));
             const bool okc = (EXACT || c < C) && !(isn || isz);
             obs.x[c] = okc ? x : (T)0; obs.y[c] = okc ? y : (T)0; obs.w[c] = okc ? w : (T)0;
             if (EXACT || c < C) accum_camera<1>(N, cams[c].P, (double)obs.x[c], (double)obs.y[c], (double)obs.w[c]);
@@ -656,6 +663,9 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
         double q[3];
         smallest_eigvec(N, q);
         prefetch(q[0]);
+        // (the reprojection pass converts x and y again: kept as doubles through the eigen-solve they are 16 registers more)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(obs.x[c]), "+v"(obs.y[c]));
         if (C - V < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }  // common.py:347: fewer than 4 rows
         double e;
         {
@@ -730,10 +740,11 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             for (int i = 0; i < 8; ++i) {
                 if (EXACT || c0 + i < C) {
                     const T x = h.x[i], y = h.y[i], w = h.w[i];
-                    const bool isn = !(w == w) || ((double)w < a.lik_thr);
+                    const bool isn = !(w == w) || (w < lik_t);
                     const bool isz = (w == (T)0) && !isn;
                     nanmask |= isn ? (1u << (c0 + i)) : 0u;
                     zeromask |= isz ? (1u << (c0 + i)) : 0u;
+                    asm volatile("" : "+v"(nanmask), "+v"(zeromask));
                     const bool ok = !(isn || isz);
                     accum_camera<1>(N, cams[c0 + i].P, (double)(ok ? x : (T)0), (double)(ok ? y : (T)0), (double)(ok ? w : (T)0));
                 }
