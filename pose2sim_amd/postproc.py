@@ -51,64 +51,78 @@ def sort_people_sports2d(keyptpre, keypt, max_dist=None):
 
 def _interpolate_column(vals, labels, max_gap, kind):
     """One column of interpolate_zeros_nans (common.py:669-712) on arrays: vals [F] with labels [F] (the frame numbers
-    interp1d sees as abscissae).  Samples that are NaN or 0 are replaced by scipy's interp1d through the others
+    interp1d sees as abscissae, increasing).  Samples that are NaN or 0 are replaced by scipy's interp1d through the others
     ('extrapolate' beyond the ends) unless they sit in a run of more than max_gap of them; with 4 or fewer good samples
-    the column comes back untouched (None)."""
+    the column comes back untouched (None).  Returns (positions, values): the samples to overwrite -- the interpolant is
+    evaluated where it is needed only (the same numbers as evaluating it everywhere and keeping those)."""
     good = ~(np.isnan(vals) | (vals == 0))
     if int(good.sum()) <= 4:
         return None
-    if kind is None:
-        f_interp = interpolate.interp1d(labels[good], vals[good], kind='linear', bounds_error=False)
-    else:
-        f_interp = interpolate.interp1d(labels[good], vals[good], kind=kind, fill_value='extrapolate', bounds_error=False)
-    out = np.where(good, vals, f_interp(labels))
     bad_pos = np.flatnonzero(~good)
-    if bad_pos.size:
-        # runs of consecutive bad labels longer than max_gap go back to NaN (:704-710)
-        bad_labels = labels[bad_pos]
-        starts = np.concatenate(([0], np.flatnonzero(np.diff(bad_labels) > 1) + 1))
-        lengths = np.diff(np.concatenate((starts, [bad_pos.size])))
-        for s0, ln in zip(starts[lengths > max_gap], lengths[lengths > max_gap]):
-            out[bad_pos[s0:s0 + ln]] = np.nan
-    return out
+    if not bad_pos.size:
+        return bad_pos, vals[:0]
+    if kind is None:
+        f_interp = interpolate.interp1d(labels[good], vals[good], kind='linear', bounds_error=False, assume_sorted=True)
+    else:
+        f_interp = interpolate.interp1d(labels[good], vals[good], kind=kind, fill_value='extrapolate', bounds_error=False, assume_sorted=True)
+    new = f_interp(labels[bad_pos])
+    # runs of consecutive bad labels longer than max_gap stay NaN (:704-710)
+    bad_labels = labels[bad_pos]
+    starts = np.concatenate(([0], np.flatnonzero(np.diff(bad_labels) > 1) + 1))
+    lengths = np.diff(np.concatenate((starts, [bad_pos.size])))
+    for s0, ln in zip(starts[lengths > max_gap], lengths[lengths > max_gap]):
+        new[s0:s0 + ln] = np.nan
+    return bad_pos, new
 
 
 def interpolate_zeros_nans(col, *args):
     """The reference's per-column entry (common.py:669-712) for a pandas column: args = (N, kind) | (kind,) | ()."""
     import pandas as pd
     max_gap, kind = (args if len(args) == 2 else (np.inf, args[0] if args else None))
-    out = _interpolate_column(np.asarray(col, dtype=np.float64), np.asarray(col.index), max_gap, kind)
-    return col if out is None else pd.Series(out, index=col.index, name=getattr(col, 'name', None))
+    vals = np.array(col, dtype=np.float64)
+    patch = _interpolate_column(vals, np.asarray(col.index), max_gap, kind)
+    if patch is None:
+        return col
+    vals[patch[0]] = patch[1]
+    return pd.Series(vals, index=col.index, name=getattr(col, 'name', None))
 
 
 def interpolate_gaps(coords, labels, max_gap, kind):
-    """Every column of coords [F][3 K] through the gap interpolation (triangulation.py:889-894: all columns or, if one of
-    them fails, none -- the caller logs the reference's warning).  Returns the new array."""
-    out = coords.copy()
-    for c in range(coords.shape[1]):
-        col = _interpolate_column(coords[:, c], labels, max_gap, kind)
-        if col is not None:
-            out[:, c] = col
-    return out
+    """Every column of coords [F][3 K] through the gap interpolation, IN PLACE (triangulation.py:889-894: all columns or,
+    if one of them fails, none -- the caller logs the reference's warning; the overwritten samples are put back then).
+    Only the gaps are touched: at 100 k frames the table is 60 MB and a copy of it costs more than the interpolation."""
+    undo = []
+    try:
+        for c in range(coords.shape[1]):
+            patch = _interpolate_column(coords[:, c], labels, max_gap, kind)
+            if patch is not None and patch[0].size:
+                undo.append((c, patch[0], coords[patch[0], c]))
+                coords[patch[0], c] = patch[1]
+    except Exception:
+        for c, pos, old in undo:
+            coords[pos, c] = old
+        raise
+    return coords
 
 
 def fill_gaps(coords, how):
     """triangulation.py:922-926.  'last_value': every gap takes the last valid value before it, leading gaps the first
     valid one after them, and what is still missing (a column never seen) or +inf becomes 0; 'zeros': NaN and +inf
-    become 0; anything else leaves the gaps."""
+    become 0; anything else leaves the gaps.  IN PLACE, column by column (one frame-long temporary at a time)."""
     if how not in ('last_value', 'zeros'):
         return coords
-    out = coords.copy()
-    if how == 'last_value':
-        F = out.shape[0]
-        rows = np.arange(F)[:, None]
-        seen = ~np.isnan(out)
-        last = np.maximum.accumulate(np.where(seen, rows, -1), axis=0)                 # row of the last valid sample, or -1
-        nxt = np.minimum.accumulate(np.where(seen, rows, F)[::-1], axis=0)[::-1]       # row of the next valid sample, or F
-        src = np.where(last >= 0, last, np.minimum(nxt, F - 1))
-        filled = np.take_along_axis(out, src, axis=0)
-        out = np.where((last >= 0) | (nxt < F), filled, np.nan)
-    out[np.isnan(out) | (out == np.inf)] = 0
+    out = coords
+    F = out.shape[0]
+    rows = np.arange(F)
+    for c in range(out.shape[1]):
+        col = out[:, c]
+        missing = np.isnan(col)
+        if how == 'last_value' and missing.any() and not missing.all():
+            last = np.maximum.accumulate(np.where(missing, -1, rows))          # row of the last valid sample, or -1
+            first = int(np.argmin(missing))                                    # leading gaps: the first valid sample
+            col[missing] = col[np.where(last >= 0, last, first)[missing]]
+            missing = np.isnan(col)
+        col[missing | (col == np.inf)] = 0
     return out
 
 
