@@ -708,7 +708,9 @@ def main():
                                     'p2s_tri_fused_kernel (round 2: streaming pass + in-wave fp64 subset search, one launch)'
                                     if (fused and args.tri_path != 'worklist') else
                                     'p2s_tri_level0_kernel + p2s_tri_search_kernel (one pass of the path)'),
-                         'kernel_ms': k_ms, 'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_launch': n_units},
+                         'kernel_ms': k_ms, 'algorithmic_bytes_per_unit': 12 * C + 32, 'units_per_step': n_units,
+                         # the one-launch kernels take the shard in chunks of < 2^31 bytes of observations (32-bit offsets)
+                         'launches_per_step': (-(-n_blocks // max(16, ((1 << 31) // (C * K * 12)) // 16 * 16))) if fused else None},
         }
         if multi:
             # the split a reader needs to judge the scaling: the all-gather moves 24 B per unit (the points) and 16 B per

@@ -99,8 +99,15 @@ for cfg in ('cfg2', 'cfg3', 'cfg4', 'cfg5_tenth'):
                 print(cfg, r)
         tri = [r for r in rows if r[0].startswith('p2s_tri_')]
         if tri:
-            # one chunk per step: one launch of each triangulation kernel per step
-            traffic[cfg] = {'bytes_per_step': sum(r[6] for r in tri), 'kernels': [r[0] for r in tri],
+            # a step is `launches_per_step` launches of the triangulation kernel (bench.py's line says how many: shards of
+            # more than 2^31 bytes of observations go in chunks); the counters are averages per launch
+            per_step = 1
+            try:
+                line = [l for l in open(os.path.join(SRC, f'bench_{cfg}.json' if cfg != 'cfg2' else 'bench_cfg2_default.json')) if l.startswith('{')][-1]
+                per_step = json.loads(line)['roofline'].get('launches_per_step') or 1
+            except Exception as exc:
+                print(cfg, 'launches per step unknown:', exc)
+            traffic[cfg] = {'bytes_per_step': per_step * sum(r[6] for r in tri), 'launches_per_step': per_step, 'kernels': [r[0] for r in tri],
                             'source': f'profiles/{R}/pmc_hbm_traffic_{cfg}.csv', 'sources_sha1': sources_fingerprint()}
             print(cfg, 'traffic per step', traffic[cfg]['bytes_per_step'])
 if traffic:
