@@ -634,10 +634,10 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                         double e = kInf;
                         if (__any(alive)) { e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q); st_pcams += (unsigned long long)C * ngo; }
                         const uint32_t rt = rank_subset(S, C, level, sBinom);
-                        if (alive && (brank == 0xffffffffu || e < be || (e == be && rt < brank))) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
+                        if (alive && better_candidate(e, rt, be, brank)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
                     } else {
                         const double e = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
-                        if (go && (e < be || brank == 0xffffffffu)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
+                        if (go && (brank == 0xffffffffu || e < be || (be != be && e == e))) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
                     }
                 }
 
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(256, 3) p2s_tri_search_kernel(const P2sTriArgs
                 for (int off = G >> 1; off > 0; off >>= 1) {
                     const double oe = shfl_d(be, lane ^ off);
                     const uint32_t orank = __shfl(brank, lane ^ off, 64);
-                    const bool take = (orank != 0xffffffffu) && (brank == 0xffffffffu || oe < be || (oe == be && orank < brank));
+                    const bool take = better_candidate(oe, orank, be, brank);
                     const double t0 = shfl_d(bq0, lane ^ off), t1 = shfl_d(bq1, lane ^ off), t2 = shfl_d(bq2, lane ^ off);
                     const uint32_t tS = __shfl(bS, lane ^ off, 64);
                     if (take) { be = oe; brank = orank; bq0 = t0; bq1 = t1; bq2 = t2; bS = tS; }

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
                 st_cams += (unsigned long long)C * (unsigned long long)__popcll(__ballot(go));
             }
             const uint32_t rt = rank_subset(S, C, level, sBinom);             // rank in itertools order: ties, reduction
-            if (alive && (brank == kNone || err < be || (err == be && rt < brank))) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
+            if (alive && better_candidate(err, rt, be, brank)) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
             if (LRSWAP && !skip_swap && __any(alive && err <= thr)) {
                 skip_swap = true;
                 if (lane == 0) atomicOr(plain_ok, 1u);
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
         for (int off = 32; off > 0; off >>= 1) {
             const double oe = shfl_d(be, lane ^ off);
             const uint32_t orank = __shfl(brank, lane ^ off, 64);
-            const bool take = (orank != kNone) && (brank == kNone || oe < be || (oe == be && orank < brank));
+            const bool take = better_candidate(oe, orank, be, brank);
             const double t0 = shfl_d(bq0, lane ^ off), t1 = shfl_d(bq1, lane ^ off), t2 = shfl_d(bq2, lane ^ off);
             const uint32_t tS = __shfl(bS, lane ^ off, 64);
             if (take) { be = oe; brank = orank; bq0 = t0; bq1 = t1; bq2 = t2; bS = tS; }
@@ -309,13 +309,13 @@ __global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a,
         uint32_t brank = kNone, srank = kNone, bt = 0, st = 0;         // bt / st: ticket holding the candidate
         for (uint32_t c = lane; c < e->n_chunks; c += 64) {
             const P2sDeepPartial &p = d.partials[e->first_ticket + c];
-            if (p.rank != kNone && (brank == kNone || p.e < be || (p.e == be && p.rank < brank))) { be = p.e; brank = p.rank; bt = e->first_ticket + c; }
+            if (better_candidate(p.e, p.rank, be, brank)) { be = p.e; brank = p.rank; bt = e->first_ticket + c; }
             if (LRSWAP && p.srank != kNone && (srank == kNone || p.se < se || (p.se == se && p.srank < srank))) { se = p.se; srank = p.srank; st = e->first_ticket + c; }
         }
         for (int off = 32; off > 0; off >>= 1) {
             const double oe = shfl_d(be, lane ^ off);
             const uint32_t orank = __shfl(brank, lane ^ off, 64), ot = __shfl(bt, lane ^ off, 64);
-            if ((orank != kNone) && (brank == kNone || oe < be || (oe == be && orank < brank))) { be = oe; brank = orank; bt = ot; }
+            if (better_candidate(oe, orank, be, brank)) { be = oe; brank = orank; bt = ot; }
             if (LRSWAP) {
                 const double xe = shfl_d(se, lane ^ off);
                 const uint32_t xrank = __shfl(srank, lane ^ off, 64), xt = __shfl(st, lane ^ off, 64);

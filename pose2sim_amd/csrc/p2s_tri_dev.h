@@ -15,6 +15,14 @@ namespace {
 
 constexpr double kInf = __builtin_huge_val();
 
+// np.nanargmin's order on the candidates (error, rank) of a level (triangulation.py:500-503): a number beats a NaN, then
+// the lower error, then the lower rank (the first index); rank 0xffffffff = no candidate yet.  Among NaNs only the
+// lowest rank stays (np.nanargmin raises when every error is NaN; the unit then ends as not triangulated either way).
+__device__ __forceinline__ bool better_candidate(double e, uint32_t r, double be, uint32_t br) {
+    const bool en = !(e == e), bn = !(be == be);
+    return (r != 0xffffffffu) && ((br == 0xffffffffu) || (bn && !en) || (en == bn && (e < be || ((e == be || en) && r < br))));
+}
+
 // Calibration is read-only for the whole launch: going through the constant address space lets
 // every uniform-index access become a scalar (SMEM) load and the value an SGPR operand.
 typedef const __attribute__((address_space(4))) P2sCam *cam_cptr;
@@ -368,15 +376,23 @@ __device__ __forceinline__ void for_each_cam(int C, F &&f) {
     }
 }
 
+// Coordinates that are numbers (not inf, not NaN; a pair whose magnitudes sum to inf counts as not finite either).
+template <typename T>
+__device__ __forceinline__ bool finite_xy(T x, T y) { return (__builtin_fabs(x) + __builtin_fabs(y)) < (T)__builtin_huge_val(); }
+__device__ __forceinline__ bool finite_xy(float x, float y) { return (__builtin_fabsf(x) + __builtin_fabsf(y)) < __builtin_huge_valf(); }
+
 // Level-0 pass over all cameras: classify each camera (NaN / zero likelihood) and accumulate the
 // normal matrix of the valid ones.  Branch-free: an invalid camera enters with weight 0.
+// A camera whose coordinates are not finite although its likelihood passes is taken as a missing detection (the NaN
+// class): the reference keeps it among the valid cameras, finds every subset that contains it at error inf and arrives at
+// the same point, error, exclusion count and excluded-camera set one search level later.
 template <typename T, int CT, typename OBS>
 __device__ __forceinline__ void classify_and_accumulate(cam_cptr cams, int C, const OBS &o, double N[10],
                                                          uint32_t &nanmask, uint32_t &zeromask) {
     for_each_cam<CT>(C, [&](int c) {
         T x, y, w;
         o.rawT(c, x, y, w);
-        const bool isn = !(w == w) || ((double)w < o.lik_thr);
+        const bool isn = !(w == w) || ((double)w < o.lik_thr) || !finite_xy(x, y);
         const bool isz = (w == (T)0) && !isn;
         nanmask |= isn ? (1u << c) : 0u;
         zeromask |= isz ? (1u << c) : 0u;

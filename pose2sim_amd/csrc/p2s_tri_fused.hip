@@ -293,14 +293,16 @@ __global__ void __launch_bounds__(64, 3) p2s_tri_fused_kernel(const P2sTriArgs a
                         cam_cptr cams_here = cams;
                         asm volatile("" : "+s"(cams_here));
                         const double e = mean_error<T, false, CT>(cams_here, C, sobs, kept, q);
-                        if (go && (e < be || brank == kNone)) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
+                        // (a lane meets its candidates in rising rank: a lower error wins, and a number replaces a NaN --
+                        // np.nanargmin, triangulation.py:500-503)
+                        if (go && (brank == kNone || e < be || (be != be && e == e))) { be = e; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = r; bS = S; }
                     }
                     double ge = be;
                     uint32_t grank = brank;
                     for (int off = G >> 1; off > 0; off >>= 1) {
                         const double oe = __shfl_xor(ge, off, 64);
                         const uint32_t orank = (uint32_t)__shfl_xor((int)grank, off, 64);
-                        const bool take = (orank != kNone) && (grank == kNone || oe < ge || (oe == ge && orank < grank));
+                        const bool take = better_candidate(oe, orank, ge, grank);
                         if (take) { ge = oe; grank = orank; }
                     }
                     grank = (uint32_t)__shfl((int)grank, lane & ~(G - 1), 64);

@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const T x = cur.x[c], y = cur.y[c], w = cur.w[c];
-            const bool isn = (EXACT || c < C) && (!(w == w) || (w < lik_t));
+            const bool isn = (EXACT || c < C) && (!(w == w) || (w < lik_t) || !finite_xy(x, y));   // (see classify_and_accumulate)
             const bool isz = (EXACT || c < C) && (w == (T)0) && !isn;
             nanmask |= isn ? (1u << c) : 0u;
             zeromask |= isz ? (1u << c) : 0u;
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(64, P2S_POOL_WPS) p2s_tri_pool_kernel(const P2
             for (int i = 0; i < 8; ++i) {
                 if (EXACT || c0 + i < C) {
                     const T x = h.x[i], y = h.y[i], w = h.w[i];
-                    const bool isn = !(w == w) || (w < lik_t);
+                    const bool isn = !(w == w) || (w < lik_t) || !finite_xy(x, y);
                     const bool isz = (w == (T)0) && !isn;
                     nanmask |= isn ? (1u << (c0 + i)) : 0u;
                     zeromask |= isz ? (1u << (c0 + i)) : 0u;

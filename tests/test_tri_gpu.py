@@ -171,6 +171,39 @@ def test_edge_cases(engine):
     _compare(Qa[:60], ea[:60], na[:60], ma[:60], Qr, er, nr, mr, 'K=1')
 
 
+def test_non_finite_coordinates_with_a_valid_likelihood(engine):
+    """A camera whose coordinates are inf or NaN while its likelihood passes the threshold.  The reference keeps it among
+    the valid cameras: level 0 cannot be solved (every reprojection is NaN -> euclidean_distance's all-NaN rule -> inf), every
+    subset that keeps the camera stays at inf, and np.nanargmin (triangulation.py:500-503) finds the subset without it one
+    level later.  The kernels take such a camera as a missing detection at level 0 (classify_and_accumulate): the same point,
+    error, exclusion count and excluded-camera set, on every kernel path.  Units left with fewer finite cameras than
+    min_cameras are not triangulated either way; there the reference reports the first cameras of its last level and
+    the kernels every camera."""
+    from oracle import triangulation_ref as tr
+    from pose2sim_amd import synth
+    for C, min_cams in ((6, 2), (8, 3), (12, 4)):
+        wl = synth.make_config(40, C, 7, 1, seed=70 + C, p_outlier=0.0, p_lowlik=0.0, p_missing_cam=0.0)
+        x = wl['xyl'].copy()
+        x[0:8, 0, 1, :, 0] = np.inf                      # x of camera 1
+        x[8:16, 0, 2, :, 1] = -np.inf                    # y of camera 2
+        x[16:24, 0, 0, :, 0] = np.nan                    # NaN coordinate, likelihood intact
+        x[24:32, 0, 3, :, 0] = np.inf
+        x[24:32, 0, 4, :, 1] = np.nan                    # two such cameras: the reference goes to level 2
+        x[32:36, 0, :, :, 0] = np.inf                    # every camera
+        engine.set_calibration(wl['P'])
+        prm = engine.tri_params(15.0, 0.3, min_cams)
+        with np.errstate(all='ignore'):
+            Qr, er, nr, mr = tr.triangulate_batch(x, wl['P'], None, list(range(7)), 0.3, 15.0, min_cams)
+        Q, err, nex, mask = engine.triangulate(x, prm)
+        rest = np.r_[0:32, 36:40]
+        _compare(Q[rest], err[rest], nex[rest], mask[rest], np.asarray(Qr)[rest], np.asarray(er)[rest], np.asarray(nr)[rest],
+                 np.asarray(mr)[rest], f'non-finite coordinates, C={C}')
+        assert not np.isnan(err[0:32]).any()
+        assert (nex[0:24] == 1).all() and (nex[24:32] == 2).all() and (mask[24:32] == 0b11000).all()
+        assert np.isnan(np.asarray(er)[32:36]).all() and np.isnan(err[32:36]).all() and np.isnan(Q[32:36]).all()
+        assert (nex[32:36] == C).all() and (mask[32:36] == (1 << C) - 1).all()
+
+
 def test_bad_arguments(engine):
     from pose2sim_amd._lib import P2sError
     from pose2sim_amd import synth
@@ -360,7 +393,7 @@ def test_pooled_search_slots_and_tile_pairing(C, p_outlier, F, singles_pct):
     ('3 cameras', 6_000, 3, 26, 2, False, dict(p_outlier=0.10)),
     ('5 cameras x 131 keypoints', 800, 5, 131, 3, False, dict(p_outlier=0.10, p_missing_cam=0.05)),
 ])
-@pytest.mark.parametrize('tiles', [2, 3, 4])
+@pytest.mark.parametrize('tiles', [2, 3, 4, 5, 6])
 def test_screen_changes_nothing(name, F, C, K, min_cams, f64, gen, tiles):
     """The pooled kernel's fp32 screen decides which camera subsets reach the fp64 evaluation and nothing else: with the
     screen off (every candidate evaluated in fp64) every output bit is the same, on seven workloads and for 2, 3 and 4
