@@ -613,11 +613,17 @@ def main():
     # 0.181 ms after 50 ms, 200 ms or 1 s of the same steps (profiles/r03/preroll.log).  Untimed, reported in the line.
     if args.preroll_ms > 0:
         t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms:
+        more = True
+        while more:
             for _ in range(20):
                 step()
             drain()
             torch.cuda.synchronize()
+            more = (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms
+            if multi:                                  # every rank runs the same number of steps (they hold collectives)
+                flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = bool(int(flag.item()))
     for _ in range(args.warmup):
         step()
     drain()
