@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(64) p2s_deep_plan_kernel(const P2sDeepArgs d, 
             e->first_ticket = first;
             e->n_chunks = chunks;
             e->pad0 = 0;                                    // "a plain candidate of this level is under the threshold" (eval kernel)
+            e->pad1 = 0x7f800000u;                          // the level's best plain error so far, as a float rounded up (eval kernel)
             for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[first + c] = i; d.sched_chunk[first + c] = c; }
         }
         const unsigned long long taken = __ballot(take);
@@ -187,6 +188,13 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
         // candidates of that entry from its next round on.  Exact whatever the timing: the reduction ignores them then.
         uint32_t *plain_ok = const_cast<uint32_t *>(&e->pad0);
         bool skip_swap = false;
+        // The waves that work on the other chunks of this level share their best plain error: a wave whose own chunk holds
+        // nothing good -- in the ranked enumeration every chunk but the first -- would otherwise prune against its own
+        // best only.  One word per entry, the bits of a non-negative float rounded UP from the double (atomicMin on the bits
+        // orders like the values): always an upper bound of the level's minimum, so what it prunes cannot be the argmin,
+        // whatever the timing (the candidate that holds the minimum, and any tie of it, stay under the bound).
+        uint32_t *shared_best = const_cast<uint32_t *>(&e->pad1);
+        double published = kInf;
         for (uint32_t r0 = r_begin; r0 < r_end; r0 += 64) {
             const uint32_t r = r0 + lane;
             bool go = r < r_end;
@@ -220,7 +228,14 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
             if (nkept < 2) { q[0] = d_nan(); q[1] = d_nan(); q[2] = d_nan(); }
             bool alive = go;
             if (prune) {
-                const double bw = wave_min_d(be);               // any finished candidate of the wave bounds the level's minimum
+                const double own = wave_min_d(be);              // any finished candidate of the wave bounds the level's minimum
+                if (own < published) {                          // (wave-uniform) tell the other chunks' waves
+                    published = own;
+                    float up = (float)own;
+                    if ((double)up < own) up = nextafterf(up, __builtin_huge_valf());
+                    if (lane == 0) atomicMin(shared_best, __float_as_uint(up));
+                }
+                const double bw = fmin(own, (double)__uint_as_float(__hip_atomic_load(shared_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
                 // with L/R-swap candidates in play the plain minimum of a FAILED level still reports its camera count
                 // when a swap candidate rescues the level (triangulation.py:576-579): only the best-so-far bounds then
                 const double bmean = (last_level || (LRSWAP && M > 2)) ? bw : fmin(bw, thr);
