@@ -456,6 +456,7 @@ def main():
     ap.add_argument('--tri-path', default='auto', choices=['auto', 'worklist', 'onetile', 'twotiles', 'pooled'], help='kernel experiments (p2s_set_tuning)')
     ap.add_argument('--no-screen', action='store_true', help='kernel experiments: pooled kernel without its fp32 screen (P2S_TUNE_SCREEN 0)')
     ap.add_argument('--pool-tiles', type=int, default=0, help='kernel experiments: P2S_TUNE_POOL_TILES')
+    ap.add_argument('--deep-min', type=int, default=-1, help='kernel experiments: P2S_TUNE_DEEP_MIN_SUBSETS')
     ap.add_argument('--preroll-ms', type=float, default=100.0,
                     help='run the step untimed for this long before the W warmup steps: an idle MI355X needs tens of ms of load '
                          'before it runs at its sustained clocks (a 20-step run read 13 %% slower per kernel without; 0 = off)')
@@ -550,6 +551,8 @@ def main():
                                               'twotiles': Engine.TRI_PATH_TWO_TILES, 'pooled': Engine.TRI_PATH_POOLED}[args.tri_path])
     if args.no_screen:
         eng.set_tuning(Engine.TUNE_SCREEN, 0)
+    if args.deep_min >= 0:
+        eng.set_tuning(Engine.TUNE_DEEP_MIN_SUBSETS, args.deep_min)
     if args.pool_tiles:
         eng.set_tuning(Engine.TUNE_POOL_TILES, args.pool_tiles)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -80,9 +80,13 @@ struct P2sTriArgs {
 };
 
 // ---- deep levels of the search, spread over the GPU (p2s_tri_deep.hip) ----------------------------------------------
+#ifndef P2S_DEEP_CHUNK
 #define P2S_DEEP_CHUNK 16384u            // consecutive subset ranks one wave evaluates per ticket (256 rounds of 64 lanes)
-#define P2S_DEEP_MIN_SUBSETS 16384u      // a level with more subsets than this leaves the search kernel's wave (C(32, 4) = 36 k
-                                         // and beyond: 5 % of the units of the 32-camera shard; the deep list holds 2^19)
+#endif
+#define P2S_DEEP_MIN_SUBSETS 4096u       // a level with more subsets than this leaves the search kernel's wave (C(32, 3) = 4 960
+                                         // and beyond: 7 % of the units of the 32-camera shard; the deep list holds 2^19 per
+                                         // chunk of 4 M units, a unit that finds it full stays in its wave).  162 -> 142 ms on
+                                         // the tenth-shard against 16 384 (1 024 the same, 256: 180)
 #define P2S_DEEP_N_ENTRIES 0             // ctl words
 #define P2S_DEEP_N_TICKETS 1
 #define P2S_DEEP_TICKET 2
