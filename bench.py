@@ -616,12 +616,15 @@ def main():
     # 0.181 ms after 50 ms, 200 ms or 1 s of the same steps (profiles/r03/preroll.log).  Untimed, reported in the line.
     if args.preroll_ms > 0:
         t_pre = time.perf_counter()
-        more = True
+        more, batch = True, 1
         while more:
-            for _ in range(20):
+            t_b = time.perf_counter()
+            for _ in range(batch):
                 step()
             drain()
             torch.cuda.synchronize()
+            if batch == 1 and time.perf_counter() - t_b < 2e-3:
+                batch = 20                             # short steps: fewer synchronisations (a 1.4 s step stays alone)
             more = (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms
             if multi:                                  # every rank runs the same number of steps (they hold collectives)
                 flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev)
