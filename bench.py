@@ -623,8 +623,9 @@ def main():
                 step()
             drain()
             torch.cuda.synchronize()
-            if batch == 1 and time.perf_counter() - t_b < 2e-3:
-                batch = 20                             # short steps: fewer synchronisations (a 1.4 s step stays alone)
+            if batch == 1 and not multi and time.perf_counter() - t_b < 2e-3:
+                batch = 20                             # short steps: fewer synchronisations (a 1.4 s step stays alone; with
+                                                       # several ranks every rank must run the same count: one at a time)
             more = (time.perf_counter() - t_pre) * 1e3 < args.preroll_ms
             if multi:                                  # every rank runs the same number of steps (they hold collectives)
                 flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev)
