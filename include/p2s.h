@@ -14,7 +14,7 @@
  *   - "_device" entry points take DEVICE pointers and enqueue on the context's stream without
  *     synchronising; "_host" entry points take HOST pointers, copy in/out and block.  One exception:
  *     p2s_triangulate_device with more than 16 cameras (or undistortion / L/R swap and a camera count whose subset
- *     levels can exceed 16 384 subsets) reads a 4-byte count after each chunk's search to drive the deep-level
+ *     levels can exceed 4 096 subsets) reads a 4-byte count after each chunk's search to drive the deep-level
  *     rounds, i.e. it synchronises the stream.
  *   - observation tensor layout: xyl[n_blocks][C][K][3] (x px, y px, likelihood), one block
  *     per (frame, person); NaN = missing.  dtype float32 or float64 (P2S_F32 / P2S_F64).
@@ -227,8 +227,8 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
  *                         P2S_TRI_PATH_WORKLIST: always the pair
  *   P2S_TUNE_SCREEN       0: the pooled kernel sends every camera subset to the fp64 evaluation (default 1: only those
  *                         its fp32 screen cannot rule out; same results bit for bit)
- *   P2S_TUNE_POOL_TILES   tiles of 64 units a wave of the pooled kernel streams before it searches their failures (2..4,
- *                         default 3; 9-16 cameras: 2)
+ *   P2S_TUNE_POOL_TILES   tiles of 64 units a wave of the pooled kernel streams before it searches their failures (2..6,
+ *                         default 5; 9-16 cameras: always 2; up to 4 cameras: always 5)
  *   P2S_TUNE_POOL_SINGLES_PCT  share (%) of the tiles that the last workgroups of every XCD take one at a time instead
  *                         of several (default 8)
  *   P2S_TUNE_FORCE_TILED  1: the LDS-tiled streaming kernel even where observations fit in registers
@@ -236,7 +236,7 @@ int p2s_get_assoc_stats(p2s_ctx *ctx, uint64_t *out, int32_t reset);
  *   P2S_TUNE_SEARCH_JOB   work-list records a search wave takes at a time (8..64; 0 = automatic)
  *   P2S_TUNE_MAX_SUBSETS  the work-list search does not enter a level with more camera subsets than this (default
  *                         2^26; this one DOES change results -- tests of the valve only)
- *   P2S_TUNE_DEEP_MIN_SUBSETS  levels of the work-list search with more camera subsets than this (default 16 384) are
+ *   P2S_TUNE_DEEP_MIN_SUBSETS  levels of the work-list search with more camera subsets than this (default 4 096) are
  *                         cut into chunks and spread over the whole GPU instead of being walked by one wave; 0 = never
  *   P2S_TUNE_DEEP_PRUNE   0: the long levels evaluate every camera of every candidate (default 1: exact pruning, same
  *                         results)
