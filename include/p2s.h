@@ -13,9 +13,9 @@
  *   - one context per GPU per process; a context is not re-entrant.
  *   - "_device" entry points take DEVICE pointers and enqueue on the context's stream without
  *     synchronising; "_host" entry points take HOST pointers, copy in/out and block.  One exception:
- *     p2s_triangulate_device with more than 16 cameras (or undistortion / L/R swap and a camera count whose subset
- *     levels can exceed 4 096 subsets) reads a 4-byte count after each chunk's search to drive the deep-level
- *     rounds, i.e. it synchronises the stream.
+ *     p2s_triangulate_device on the work-list path (undistortion, L/R swap, or more than 16 cameras) with a camera
+ *     count whose subset levels can exceed 4 096 subsets (15 cameras or more, min_cameras permitting) reads a 4-byte
+ *     count after each chunk's search to drive the deep-level rounds, i.e. it synchronises the stream.
  *   - observation tensor layout: xyl[n_blocks][C][K][3] (x px, y px, likelihood), one block
  *     per (frame, person); NaN = missing.  dtype float32 or float64 (P2S_F32 / P2S_F64).
  *   - camera count C <= P2S_MAX_CAMS (the excluded-camera set is returned as a 32-bit mask).
