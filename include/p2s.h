@@ -181,11 +181,17 @@ int p2s_butterworth_host(p2s_ctx *ctx, int64_t n_frames, int32_t n_cols, const d
  *                        selection algorithm)
  *   P2S_FILTER_ONE_EURO  one_euro_filter_1d :87-160, forward and backward pass over every run of >= 2 samples that are
  *                        not NaN; params = {1 / frame_rate, min_cutoff, beta, d_cutoff}
+ *   P2S_FILTER_KALMAN    kalman_filter_1d :316-434: constant-acceleration Kalman filter (predict, Joseph-form update per
+ *                        sample) and, with smooth != 0, the Rauch-Tung-Striebel smoother over every run of >= 4 samples
+ *                        that are neither NaN nor 0; params = {1 / frame_rate, measurement_noise, process_noise, smooth}.
+ *                        PARITY UNPINNED: the reference takes both from filterpy (not importable where this was built);
+ *                        restated from filterpy's published algorithm
  * All pointers are HOST pointers; the call blocks. */
 #define P2S_FILTER_HAMPEL 1
 #define P2S_FILTER_GAUSSIAN 2
 #define P2S_FILTER_MEDIAN 3
 #define P2S_FILTER_ONE_EURO 4
+#define P2S_FILTER_KALMAN 5
 int p2s_filter_columns_host(p2s_ctx *ctx, int32_t kind, int64_t n_frames, int32_t n_cols, const double *data,
                             const double *params, int32_t n_params, double *out);
 /* trc_evaluate's per-frame quantities and sums (Utilities/trc_evaluate.py:114-238) for xyz [n_frames][n_markers][3]:

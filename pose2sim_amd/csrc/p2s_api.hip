@@ -857,6 +857,11 @@ int p2s_filter_columns_host(p2s_ctx *ctx, int32_t kind, int64_t n_frames, int32_
         for (int i = 0; i < 4; ++i) f.p[i] = params[i];
         if (!(f.p[0] > 0.0)) return fail(P2S_ERR_INVALID_ARG, "one-euro filter: dt must be positive");
         break;
+    case P2S_FILTER_KALMAN:
+        if (n_params != 4) return fail(P2S_ERR_INVALID_ARG, "Kalman filter: params = {dt, measurement_noise, process_noise, smooth}");
+        for (int i = 0; i < 4; ++i) f.p[i] = params[i];
+        if (!(f.p[0] > 0.0)) return fail(P2S_ERR_INVALID_ARG, "Kalman filter: dt must be positive");
+        break;
     default: return fail(P2S_ERR_INVALID_ARG, "unknown column filter %d", kind);
     }
     if (n_frames == 0 || n_cols == 0) return P2S_OK;
@@ -870,8 +875,8 @@ int p2s_filter_columns_host(p2s_ctx *ctx, int32_t kind, int64_t n_frames, int32_
     if ((rc = ctx->in.ensure(bytes)) != P2S_OK) return rc;
     if ((rc = ctx->q.ensure(bytes)) != P2S_OK) return rc;
     f.in = (const double *)ctx->in.p; f.out = (double *)ctx->q.p;
-    if (kind == P2S_FILTER_ONE_EURO) {
-        if ((rc = ctx->aux0.ensure(bytes)) != P2S_OK) return rc;
+    if (kind == P2S_FILTER_ONE_EURO || kind == P2S_FILTER_KALMAN) {
+        if ((rc = ctx->aux0.ensure(kind == P2S_FILTER_KALMAN ? 12 * bytes : bytes)) != P2S_OK) return rc;
         f.work = (double *)ctx->aux0.p;
     }
     if (kind == P2S_FILTER_GAUSSIAN) {

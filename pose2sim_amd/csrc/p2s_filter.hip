@@ -220,6 +220,130 @@ __global__ void __launch_bounds__(64) p2s_one_euro_kernel(const P2sColFilterArgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// kalman_filter_1d (filtering.py:316-434): constant-acceleration Kalman filter of one coordinate (state position, velocity,
+// acceleration; the measurement is the position) over every run of >= 4 samples that are neither NaN nor 0, then the
+// Rauch-Tung-Striebel smoother.  The reference builds it from filterpy (KalmanFilter.batch_filter: predict, then update in
+// Joseph form, per sample; rts_smoother) -- filterpy is not importable here, so this follows its published algorithm and
+// is PARITY UNPINNED (checked against oracle/filtering_ref.py only).  One lane per column; the forward pass leaves its
+// means and covariances (12 doubles per sample) in `work` for the smoother.
+struct M3 { double m[9]; };
+__device__ __forceinline__ M3 mul3(const M3 &A, const M3 &B) {
+    M3 C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return C;
+}
+__device__ __forceinline__ M3 transpose3(const M3 &A) {
+    M3 T;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T.m[3 * i + j] = A.m[3 * j + i];
+    return T;
+}
+__device__ __forceinline__ M3 inverse3(const M3 &A) {
+    const double *a = A.m;
+    const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const double id = 1.0 / (a[0] * c00 + a[1] * c01 + a[2] * c02);
+    M3 R;
+    R.m[0] = c00 * id; R.m[1] = (a[2] * a[7] - a[1] * a[8]) * id; R.m[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    R.m[3] = c01 * id; R.m[4] = (a[0] * a[8] - a[2] * a[6]) * id; R.m[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    R.m[6] = c02 * id; R.m[7] = (a[1] * a[6] - a[0] * a[7]) * id; R.m[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    return R;
+}
+
+__global__ void __launch_bounds__(64) p2s_kalman_kernel(const P2sColFilterArgs a) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= a.n_cols) return;
+    const int64_t F = a.n_frames, S = a.n_cols;
+    const double *in = a.in + col;
+    double *out = a.out + col;
+    double *work = a.work + (size_t)col * 12;                          // [frame][col][12]
+    const int64_t WS = S * 12;
+    const double dt = a.p[0], meas = a.p[1], proc = a.p[2];
+    const bool smooth = a.p[3] != 0.0;
+    const M3 Fm{{1.0, dt, dt * dt / 2, 0.0, 1.0, dt, 0.0, 0.0, 1.0}};                              // :355-359
+    const M3 Ft = transpose3(Fm);
+    const double var = proc * proc, R = meas * meas;
+    const M3 Q{{.25 * dt * dt * dt * dt * var, .5 * dt * dt * dt * var, .5 * dt * dt * var,        // Q_discrete_white_noise(3, dt, var)
+                .5 * dt * dt * dt * var, dt * dt * var, dt * var,
+                .5 * dt * dt * var, dt * var, var}};
+    auto usable = [](double v) { return (v == v) && (v != 0.0); };     // :421
+    int64_t f = 0;
+    while (f < F) {
+        const double v = in[f * S];
+        if (!usable(v)) { out[f * S] = v; ++f; continue; }
+        int64_t r = f + 1;
+        while (r < F && usable(in[r * S])) ++r;
+        if (r - f < 4) {                                               // :428: shorter runs stay as they are
+            for (int64_t i = f; i < r; ++i) out[i * S] = in[i * S];
+            f = r;
+            continue;
+        }
+        // initial state from the first three samples (:343-351), covariance I * measurement_noise (:377)
+        const double z0 = in[f * S], z1 = in[(f + 1) * S], z2 = in[(f + 2) * S];
+        double x0 = z0, x1 = (z1 - z0) / dt, x2 = ((z2 - z1) / dt - (z1 - z0) / dt) / dt;
+        M3 P{{meas, 0.0, 0.0, 0.0, meas, 0.0, 0.0, 0.0, meas}};
+        for (int64_t i = f; i < r; ++i) {
+            // predict: x = F x, P = F P F^T + Q
+            const double p0 = x0 + dt * x1 + (dt * dt / 2) * x2, p1 = x1 + dt * x2, p2 = x2;
+            M3 Pp = mul3(mul3(Fm, P), Ft);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Pp.m[k] += Q.m[k];
+            // update with z (H = [1 0 0]): K = P H^T / (H P H^T + R), x += K (z - x0), P = (I - K H) P (I - K H)^T + K R K^T
+            const double y = in[i * S] - p0;
+            const double Sinv = 1.0 / (Pp.m[0] + R);
+            const double k0 = Pp.m[0] * Sinv, k1 = Pp.m[3] * Sinv, k2 = Pp.m[6] * Sinv;
+            x0 = p0 + k0 * y; x1 = p1 + k1 * y; x2 = p2 + k2 * y;
+            const M3 IKH{{1.0 - k0, 0.0, 0.0, -k1, 1.0, 0.0, -k2, 0.0, 1.0}};
+            P = mul3(mul3(IKH, Pp), transpose3(IKH));
+            const double kk[3] = {k0, k1, k2};
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int w = 0; w < 3; ++w) P.m[3 * u + w] += kk[u] * R * kk[w];
+            double *wk = work + i * WS;
+            wk[0] = x0; wk[1] = x1; wk[2] = x2;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[3 + k] = P.m[k];
+            if (!smooth) out[i * S] = x0;
+        }
+        if (smooth) {
+            // rts_smoother: from the last sample backwards, x[k] += K (x[k+1] - F x[k]), P[k] += K (P[k+1] - Pp) K^T with
+            // Pp = F P[k] F^T + Q and K = P[k] F^T Pp^-1
+            double n0 = x0, n1 = x1, n2 = x2;                          // smoothed state and covariance of sample k + 1
+            M3 Pn = P;
+            out[(r - 1) * S] = n0;
+            for (int64_t i = r - 2; i >= f; --i) {
+                const double *wk = work + i * WS;
+                const double c0 = wk[0], c1 = wk[1], c2 = wk[2];
+                M3 Pk;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Pk.m[k] = wk[3 + k];
+                M3 Pp = mul3(mul3(Fm, Pk), Ft);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Pp.m[k] += Q.m[k];
+                const M3 K = mul3(mul3(Pk, Ft), inverse3(Pp));
+                const double d0 = n0 - (c0 + dt * c1 + (dt * dt / 2) * c2), d1 = n1 - (c1 + dt * c2), d2 = n2 - c2;
+                n0 = c0 + K.m[0] * d0 + K.m[1] * d1 + K.m[2] * d2;
+                n1 = c1 + K.m[3] * d0 + K.m[4] * d1 + K.m[5] * d2;
+                n2 = c2 + K.m[6] * d0 + K.m[7] * d1 + K.m[8] * d2;
+                M3 D;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) D.m[k] = Pn.m[k] - Pp.m[k];
+                const M3 U = mul3(mul3(K, D), transpose3(K));
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Pn.m[k] = Pk.m[k] + U.m[k];
+                out[i * S] = n0;
+            }
+        }
+        f = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // trc_evaluate: one workgroup per bone (blocks [0, n_bones)) or per marker (blocks [n_bones, n_bones + n_markers)).
 __global__ void __launch_bounds__(256) p2s_trc_metrics_kernel(const P2sMetricsArgs a) {
     __shared__ double s_sum[256];
@@ -320,6 +444,7 @@ hipError_t p2s_launch_col_filter(const P2sColFilterArgs &a, hipStream_t s) {
     case P2S_FILTER_GAUSSIAN: hipLaunchKernelGGL(p2s_gauss_kernel, dim3(grid_e), dim3(256), 0, s, a); break;
     case P2S_FILTER_MEDIAN: hipLaunchKernelGGL(p2s_median_kernel, dim3(grid_e), dim3(256), 0, s, a); break;
     case P2S_FILTER_ONE_EURO: hipLaunchKernelGGL(p2s_one_euro_kernel, dim3(grid_c), dim3(64), 0, s, a); break;
+    case P2S_FILTER_KALMAN: hipLaunchKernelGGL(p2s_kalman_kernel, dim3(grid_c), dim3(64), 0, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -208,7 +208,8 @@ class Engine:
 
     def filter_columns(self, kind, data, params):
         """One of the window / recurrence filters of filtering.py on every column of data [n_frames][n_cols]
-        (include/p2s.h: P2S_FILTER_HAMPEL = 1, _GAUSSIAN = 2, _MEDIAN = 3, _ONE_EURO = 4, with their parameters)."""
+        (include/p2s.h: P2S_FILTER_HAMPEL = 1, _GAUSSIAN = 2, _MEDIAN = 3, _ONE_EURO = 4, _KALMAN = 5, with their
+        parameters)."""
         data = np.ascontiguousarray(data, dtype=np.float64)
         if data.ndim != 2:
             raise P2sError(f'data has shape {data.shape}; expected [n_frames][n_cols]')

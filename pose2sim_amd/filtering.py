@@ -11,9 +11,13 @@ What runs where:
 * ``median`` (:561-577) .................................................... p2s_median_kernel
 * ``one_euro`` (:87-160) ................................................... p2s_one_euro_kernel
 
+* ``kalman`` (:316-434) .................................................... p2s_kalman_kernel -- PARITY UNPINNED: the
+  reference takes the filter and the smoother from filterpy, which is not importable where this was built; the kernel
+  follows filterpy's published algorithm and is checked against oracle/filtering_ref.py only
+
 Coefficients and kernel weights come from the very SciPy calls the reference makes, so the kernels reproduce its numbers
-to rounding.  ``kalman``, ``gcv_spline`` and ``loess`` need filterpy / statsmodels / make_smoothing_spline, which the
-reference imports from packages that are not part of this build: they are refused with NotImplementedError.  The
+to rounding.  ``gcv_spline`` and ``loess`` need make_smoothing_spline's private GCV search / statsmodels: they are
+refused with NotImplementedError.  The
 figures of the reference (``display_figures``, ``save_filt_plots``) are a GUI matter and not produced.
 """
 import glob
@@ -24,9 +28,8 @@ import numpy as np
 
 from . import trc as trc_mod
 
-FILTER_HAMPEL, FILTER_GAUSSIAN, FILTER_MEDIAN, FILTER_ONE_EURO = 1, 2, 3, 4          # include/p2s.h
-REFUSED_TYPES = {'kalman': 'filterpy', 'gcv_spline': 'scipy.interpolate.make_smoothing_spline and its GCV search',
-                 'loess': 'statsmodels'}
+FILTER_HAMPEL, FILTER_GAUSSIAN, FILTER_MEDIAN, FILTER_ONE_EURO, FILTER_KALMAN = 1, 2, 3, 4, 5    # include/p2s.h
+REFUSED_TYPES = {'gcv_spline': 'scipy.interpolate.make_smoothing_spline and its GCV search', 'loess': 'statsmodels'}
 
 
 def _make_engine():
@@ -90,6 +93,17 @@ def one_euro_filter(data, frame_rate, min_cutoff=2.5, beta=0.9, d_cutoff=1.0, en
     return engine.filter_columns(FILTER_ONE_EURO, data, [1.0 / frame_rate, float(min_cutoff), float(beta), float(d_cutoff)])
 
 
+def kalman_filter(data, frame_rate, trust_ratio, smooth=True, engine=None):
+    """kalman_filter_1d (filtering.py:402-434) on every column: constant-acceleration Kalman filter (measurement noise 20,
+    process noise 20 * trust_ratio) and Rauch-Tung-Striebel smoother over every run of >= 4 samples that are neither NaN
+    nor 0.  PARITY UNPINNED: the reference takes both from filterpy, which is not importable here -- the kernel follows
+    filterpy's published algorithm and is checked against oracle/filtering_ref.py only."""
+    engine = engine or _make_engine()
+    measurement_noise = 20
+    return engine.filter_columns(FILTER_KALMAN, data, [1.0 / frame_rate, float(measurement_noise), float(measurement_noise * int(trust_ratio)),
+                                                       1.0 if int(smooth) else 0.0])
+
+
 def _apply(filter_type, fcfg, data, frame_rate, engine):
     """filter1d (filtering.py:632-662) for a whole matrix."""
     if filter_type == 'butterworth':
@@ -105,6 +119,9 @@ def _apply(filter_type, fcfg, data, frame_rate, engine):
     if filter_type == 'one_euro':
         p = fcfg.get('one_euro')
         return one_euro_filter(data, frame_rate, p.get('cut_off_frequency', 2.5), p.get('beta', 0.9), p.get('d_cut_off_frequency', 1.0), engine)
+    if filter_type == 'kalman':
+        p = fcfg.get('kalman')
+        return kalman_filter(data, frame_rate, p.get('trust_ratio'), p.get('smooth'), engine)
     if filter_type in REFUSED_TYPES:
         raise NotImplementedError(f"filter type '{filter_type}' needs {REFUSED_TYPES[filter_type]}, which is not part of this build")
     raise KeyError(filter_type)                                # the reference's filter_mapping[filter_type]
@@ -141,6 +158,8 @@ _TYPE_LINES = {
                                        f"Cut-off frequency {int(_sub(f, 'butterworth_on_speed').get('cut_off_frequency'))} Hz."),
     'gaussian': lambda f: f"--> Filter type: Gaussian. Standard deviation kernel: {int(_sub(f, 'gaussian').get('sigma_kernel'))}",
     'median': lambda f: f"--> Filter type: Median. Kernel size: {_sub(f, 'median').get('kernel_size')}",
+    'kalman': lambda f: (f"--> Filter type: Kalman {'smoother' if int(_sub(f, 'kalman').get('smooth')) else 'filter'}. Measurements trusted "
+                         f"{int(_sub(f, 'kalman').get('trust_ratio'))} times as much as previous data, assuming a constant acceleration process."),
 }
 
 

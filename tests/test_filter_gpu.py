@@ -257,3 +257,29 @@ def test_filter_all_with_outlier_rejection_on_the_gpu(engine, gold2):
                 _close(a, b, f'file {i} ({cfg["filtering"]["type"]})')
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+def test_kalman_kernel_against_the_restatement(engine):
+    """p2s_kalman_kernel against oracle/filtering_ref.kalman_filter_1d -- PARITY UNPINNED: the reference takes the filter
+    and the smoother from filterpy, which is not importable here, so no golden exists; both sides follow filterpy's
+    published algorithm (predict, Joseph-form update, rts_smoother).  Runs of every length around the 4-sample limit,
+    NaN and zero gaps, a column that is all NaN, filter and smoother, two trust ratios; 1e-9 relative."""
+    from oracle import filtering_ref as fr
+    from pose2sim_amd import filtering
+    rng = np.random.default_rng(33)
+    F, ncol = 3_000, 70
+    t = np.arange(F)[:, None] / 60.0
+    data = 1.0 + 0.5 * np.sin(2 * np.pi * (0.3 + rng.random(ncol)) * t) + rng.normal(0, 0.005, (F, ncol))
+    data[rng.random((F, ncol)) < 0.01] = np.nan
+    data[rng.random((F, ncol)) < 0.004] = 0.0
+    data[:, 5] = np.nan
+    data[10:13, 6] = np.nan; data[16, 6] = np.nan; data[21, 6] = 0.0           # runs of 3, 4 and more
+    for trust, smooth in ((500, True), (500, False), (20, True)):
+        got = filtering.kalman_filter(data, 60, trust, smooth, engine)
+        for c in range(0, ncol, 3):
+            _close(got[:, c], fr.kalman_filter_1d(data[:, c], 60, trust, smooth), f'kalman trust {trust} smooth {smooth} column {c}')
+        assert np.array_equal(got[:, 5], data[:, 5], equal_nan=True)
+    for F2 in (1, 3, 4, 5):
+        small = rng.normal(1, 0.1, (F2, 9))
+        want = np.stack([fr.kalman_filter_1d(small[:, c], 30, 500, True) for c in range(9)], 1)
+        _close(filtering.kalman_filter(small, 30, 500, True, engine), want, f'kalman F={F2}')
