@@ -58,6 +58,22 @@ CONFIGS = {
 }
 
 
+def native_library_record():
+    """Which C-ABI library this run loaded: its fingerprint, and the translation units this process compiled itself
+    (none when the library travelled with the snapshot and was newer than its sources)."""
+    import hashlib
+    import __graft_entry__ as entry
+    from pose2sim_amd import _lib
+    path = os.environ.get('P2S_LIB') or entry.LIB
+    rec = entry.BUILD_RECORD.get(entry.LIB, {})
+    try:
+        sha = hashlib.sha1(open(path, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        sha = None
+    return {'file': os.path.relpath(path, ROOT), 'sha1_16': sha, 'compiled_by_this_run': rec.get('recompiled', []) if rec else None,
+            'abi_version': int(_lib.load().p2s_version())}
+
+
 def make_workload(cfg, rank):
     from pose2sim_amd import skeletons, synth
     ids, names, swap = skeletons.keypoints(cfg['model'])
@@ -701,6 +717,7 @@ def main():
                        'units_per_gpu': n_units, 'input_dtype': 'f32',
                        'input_buffers_rotated': n_buf, 'input_bytes_per_buffer': in_bytes, 'generated': 'on device, per rank, from the seed',
                        'preroll_ms': args.preroll_ms,
+                       'native_library': native_library_record(),
                        'params': {'thr_px': cfg['thr'], 'lik_thr': cfg['lik'], 'min_cams': cfg['min_cams'],
                                   'undistort': cfg['undistort'], 'lr_swap': cfg['lr_swap']},
                        'accepted_fraction': ok_frac,
