@@ -41,53 +41,63 @@ __device__ __forceinline__ P2sDeepEntry *entry_at(const P2sDeepArgs &d, uint32_t
     return reinterpret_cast<P2sDeepEntry *>(d.entries + (size_t)i * d.entry_bytes);
 }
 
-// ---- plan: tickets for the entries that fit this round (one wave: 64 entries at a time, exclusive scan of their
-// chunk counts; the first entry always fits, the others while the ticket buffer lasts) -----------------------------------
-__global__ void __launch_bounds__(64) p2s_deep_plan_kernel(const P2sDeepArgs d, const uint32_t *binom, int C) {
-    const int lane = threadIdx.x;
+// ---- plan: tickets for the entries that fit this round.  One workgroup of 16 waves; wave w scans the w-th sixteenth of
+// the list 64 entries at a time (exclusive scan of their chunk counts), twice: first for its total, then -- with the
+// totals of the waves before it -- for the tickets themselves.  An entry is taken while the tickets up to and including
+// its own fit the buffer (the running sum never decreases, so the first entry that does not fit closes the round for
+// everything after it; the very first entry always fits: max_tickets >= max_subsets / P2S_DEEP_CHUNK, checked on the host).
+__global__ void __launch_bounds__(1024) p2s_deep_plan_kernel(const P2sDeepArgs d, const uint32_t *binom, int C) {
+    __shared__ uint32_t sTickets[16], sPending[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = min(d.ctl[P2S_DEEP_N_ENTRIES], d.capacity);
-    uint32_t tickets = 0, pending = 0;
-    bool full = false;
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        P2sDeepEntry *e = i < n ? entry_at(d, i) : nullptr;
-        const bool live = e && e->state != P2S_DEEP_DONE;
-        pending += (uint32_t)__popcll(__ballot(live));
-        const uint32_t chunks = live ? (binom[C * 33 + e->level] + P2S_DEEP_CHUNK - 1) / P2S_DEEP_CHUNK : 0u;
-        uint32_t incl = chunks;                                             // inclusive scan over the wave
+    const uint32_t per = ((n + 15u) / 16u + 63u) / 64u * 64u;          // entries per wave, whole rounds of 64
+    const uint32_t i_begin = min(n, (uint32_t)wave * per), i_end = min(n, i_begin + per);
+    uint32_t base = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t tickets = base, pending = 0;
+        for (uint32_t i0 = i_begin; i0 < i_end; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            P2sDeepEntry *e = i < i_end ? entry_at(d, i) : nullptr;
+            const bool live = e && e->state != P2S_DEEP_DONE;
+            pending += (uint32_t)__popcll(__ballot(live));
+            const uint32_t chunks = live ? (binom[C * 33 + e->level] + P2S_DEEP_CHUNK - 1) / P2S_DEEP_CHUNK : 0u;
+            uint32_t incl = chunks;                                         // inclusive scan over the wave
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
-            if (lane >= off) incl += v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            const uint32_t first = tickets + incl - chunks;
+            if (pass == 1) {
+                const bool take = live && (first + chunks <= d.max_tickets || first == 0);
+                if (live) e->state = take ? P2S_DEEP_SCHEDULED : P2S_DEEP_WAITING;
+                if (take) {
+                    e->first_ticket = first;
+                    e->n_chunks = chunks;
+                    e->pad0 = 0;                            // "a plain candidate of this level is under the threshold" (eval kernel)
+                    e->pad1 = 0x7f800000u;                  // the level's best plain error so far, as a float rounded up (eval kernel)
+                    for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[first + c] = i; d.sched_chunk[first + c] = c; }
+                }
+                // tickets issued = the end of the last entry taken (the taken entries are a prefix of the live ones)
+                const unsigned long long taken = __ballot(take);
+                if (taken != 0ull && lane == 63 - __builtin_clzll(taken)) atomicMax(d.ctl + P2S_DEEP_N_TICKETS, first + chunks);
+            }
+            tickets += (uint32_t)__shfl((int)incl, 63, 64);
         }
-        const uint32_t first = tickets + incl - chunks;
-        // an entry is taken while everything before it was taken and it fits (the very first one always: max_tickets >=
-        // max_subsets / P2S_DEEP_CHUNK, checked on the host)
-        const bool fits = live && !full && (first + chunks <= d.max_tickets || first == 0);
-        const unsigned long long fit_mask = __ballot(fits), live_mask = __ballot(live);
-        // the first live entry that does not fit closes the round for everything after it
-        const unsigned long long miss = live_mask & ~fit_mask;
-        const unsigned long long before_miss = miss ? ((miss & (0ull - miss)) - 1ull) : ~0ull;
-        const bool take = fits && ((before_miss >> lane) & 1ull);
-        if (live) e->state = take ? P2S_DEEP_SCHEDULED : P2S_DEEP_WAITING;
-        if (take) {
-            e->first_ticket = first;
-            e->n_chunks = chunks;
-            e->pad0 = 0;                                    // "a plain candidate of this level is under the threshold" (eval kernel)
-            e->pad1 = 0x7f800000u;                          // the level's best plain error so far, as a float rounded up (eval kernel)
-            for (uint32_t c = 0; c < chunks; ++c) { d.sched_entry[first + c] = i; d.sched_chunk[first + c] = c; }
+        if (pass == 0) {
+            if (lane == 0) { sTickets[wave] = tickets; sPending[wave] = pending; }
+            __syncthreads();
+            for (int w = 0; w < wave; ++w) base += sTickets[w];
+            if (threadIdx.x == 0) {
+                uint32_t pend = 0;
+                for (int w = 0; w < 16; ++w) pend += sPending[w];
+                d.ctl[P2S_DEEP_TICKET] = 0;
+                d.ctl[P2S_DEEP_PENDING] = pend;             // the reduce kernel takes the finished ones off
+                d.ctl[P2S_DEEP_N_TICKETS] = 0;              // raised in the second pass (atomicMax of the taken entries' ends)
+                __threadfence();
+            }
+            __syncthreads();
         }
-        const unsigned long long taken = __ballot(take);
-        if (taken) {
-            const int last = 63 - __builtin_clzll(taken);
-            tickets = (uint32_t)__shfl((int)(first + chunks), last, 64);
-        }
-        full = full || (miss != 0ull);
-    }
-    if (lane == 0) {
-        d.ctl[P2S_DEEP_N_TICKETS] = tickets;
-        d.ctl[P2S_DEEP_TICKET] = 0;
-        d.ctl[P2S_DEEP_PENDING] = pending;                  // the reduce kernel takes the finished ones off
     }
 }
 
@@ -317,6 +327,10 @@ __global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a,
     const int lane = threadIdx.x;
     const double thr = a.thr;
     const uint32_t allmask = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+    // counters of this wave's entries, added to the shared ones once at the end (one atomic per entry on one address was
+    // most of this kernel's time)
+    unsigned long long st_subsets = 0, st_passes = 0, st_capped = 0;
+    uint32_t finished = 0;
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         P2sDeepEntry *e = entry_at(d, i);
         if (e->state != P2S_DEEP_SCHEDULED) continue;
@@ -354,8 +368,9 @@ __global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a,
         e->err_min = l_err; e->Q[0] = l_q0; e->Q[1] = l_q1; e->Q[2] = l_q2; e->mask = l_mask; e->n_excl = l_nexcl;
         const bool more = (l_err > thr) && (level + 1 <= e->Lmax);
         const bool cont = more && (a.binom[C * 33 + level + 1] <= a.max_subsets);
-        if (more && !cont && a.stats) atomicAdd(a.stats + 3, 1ull);                  // stopped by the safety valve
-        if (a.stats) { atomicAdd(a.stats + 1, (unsigned long long)a.binom[C * 33 + level]); if (d.prune) atomicAdd(a.stats + 5, (unsigned long long)a.binom[C * 33 + level]); atomicAdd(a.stats + 2, (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64)); }
+        if (more && !cont) ++st_capped;                                              // stopped by the safety valve
+        st_subsets += (unsigned long long)a.binom[C * 33 + level];
+        st_passes += (unsigned long long)e->n_chunks * (P2S_DEEP_CHUNK / 64);
         if (cont) {
             e->level = (uint32_t)(level + 1);
             e->state = P2S_DEEP_WAITING;
@@ -368,7 +383,15 @@ __global__ void __launch_bounds__(64) p2s_deep_reduce_kernel(const P2sTriArgs a,
             a.n_excl[gu] = (uint8_t)l_nexcl;
             a.mask[gu] = l_mask;
             e->state = P2S_DEEP_DONE;
-            atomicSub(d.ctl + P2S_DEEP_PENDING, 1u);
+            ++finished;
+        }
+    }
+    if (lane == 0) {
+        if (finished) atomicSub(d.ctl + P2S_DEEP_PENDING, finished);
+        if (a.stats) {
+            if (st_capped) atomicAdd(a.stats + 3, st_capped);
+            if (st_subsets) { atomicAdd(a.stats + 1, st_subsets); if (d.prune) atomicAdd(a.stats + 5, st_subsets); }
+            if (st_passes) atomicAdd(a.stats + 2, st_passes);
         }
     }
 }
@@ -378,9 +401,9 @@ hipError_t launch_round(const P2sTriArgs &a, const P2sDeepArgs &d, int grid_eval
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&p2s_deep_eval_kernel<T, U, L>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(p2s_deep_plan_kernel, dim3(1), dim3(64), 0, s, d, a.binom, a.C);
+    hipLaunchKernelGGL(p2s_deep_plan_kernel, dim3(1), dim3(1024), 0, s, d, a.binom, a.C);
     hipLaunchKernelGGL((p2s_deep_eval_kernel<T, U, L>), dim3(grid_eval), dim3(256), lds, s, a, d);
-    hipLaunchKernelGGL((p2s_deep_reduce_kernel<L>), dim3(256), dim3(64), 0, s, a, d);
+    hipLaunchKernelGGL((p2s_deep_reduce_kernel<L>), dim3(3072), dim3(64), 0, s, a, d);   // a wave per entry, grid-stride: 12 waves per CU
     return hipGetLastError();
 }
 
