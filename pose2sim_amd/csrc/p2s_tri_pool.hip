@@ -19,9 +19,11 @@
 // off (P2S_TUNE_SCREEN 0: every candidate survives) the outputs are bit-identical (tests/test_tri_gpu.py).
 //
 // The results of a tile leave the wave as soon as its level 0 is through (16-byte stores); the searched units' results
-// are patched over them after the search.  That takes the results' staging out of the LDS budget, so a wave can pool
-// three tiles (23 searching units on configs[1]) where round 2's kernel pooled two; the tiles are taken in straight-line
-// code, fresh waves by the dispatcher: a persistent loop over tiles streamed 15-60 % slower.
+// are patched over them after the search.  That takes the results' staging out of the LDS budget, and up to 8 cameras the
+// slot keeps no fp64 normal matrix either (tier B accumulates the kept cameras from the observations: 192 bytes per
+// slot), so a wave pools five tiles (38 searching units on configs[1]) where round 2's kernel pooled two; the tiles are
+// taken in straight-line code, fresh waves by the dispatcher: a persistent loop over tiles streamed 15-60 % slower
+// (DESIGN.md 4.9).
 //
 // 9-16 cameras: the observations are taken eight cameras at a time (48 registers of them beside the eigen-solve
 // spilled); x and y stay in registers for the reprojection pass, the lanes that park a unit read theirs again.
