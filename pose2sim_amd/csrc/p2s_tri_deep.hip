@@ -205,19 +205,32 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
         // whatever the timing (the candidate that holds the minimum, and any tie of it, stay under the bound).
         uint32_t *shared_best = const_cast<uint32_t *>(&e->pad1);
         double published = kInf;
-        for (uint32_t r0 = r_begin; r0 < r_end; r0 += 64) {
-            const uint32_t r = r0 + lane;
-            bool go = r < r_end;
+        // Every lane walks a run of consecutive ranks of the chunk (lane l: ranks r_begin + l per_lane ...): it unranks the
+        // first one and steps to the next combination with bit arithmetic -- the combination of positions p is kept as
+        // the bits C-1-p, where itertools' lexicographic order is the DECREASING order of the integers of one bit
+        // count, and the next lower one comes by Gosper's step on the complement.  (Unranking every candidate, 64
+        // consecutive ranks per round, was a walk of ~C dependent LDS reads per candidate.)  Rank 0 of the level, the
+        // most suspicious subset, is still in the chunk's first round.
+        const uint32_t per_lane = (r_end - r_begin + 63u) >> 6;
+        const uint32_t my_begin = r_begin + (uint32_t)lane * per_lane, my_end = min(r_end, my_begin + per_lane);
+        uint32_t xr = 0;
+        if (my_begin < my_end) xr = __brev(unrank_subset(my_begin, C, level, sBinom)) >> (32 - C);
+        for (uint32_t j = 0; j < per_lane; ++j) {
+            bool go = my_begin + j < my_end;
             if (LRSWAP && !skip_swap) skip_swap = __hip_atomic_load(plain_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             uint32_t S = 0;
             if (go) {
-                const uint32_t Sp = unrank_subset(r, C, level, sBinom);       // over ranked positions
-                for (uint32_t b = Sp; b != 0u; b &= b - 1) S |= 1u << sPerm[__builtin_ctz(b)];
+                for (uint32_t b = xr; b != 0u; b &= b - 1) S |= 1u << sPerm[C - 1 - __builtin_ctz(b)];   // ranked position -> camera
                 // duplicates of one effective configuration (quirk Q1): only the lexicographically first one -- padding =
                 // the lowest cameras of the excluded set -- can win
                 const uint32_t pad = S & o_d;
                 const uint32_t below = pad ? ((2u << (31 - __builtin_clz(pad))) - 1u) : 0u;
                 go = (o_d & below) == pad;
+            }
+            {   // the lane's next combination (what a lane past its run computes is never looked at)
+                const uint32_t yc = ~xr & allmask;
+                const uint32_t lowest = yc & (0u - yc), carried = yc + lowest;
+                xr = ~(carried | (((yc ^ carried) >> 2) >> __builtin_ctz(yc | 0x80000000u))) & allmask;
             }
             if (!__any(go)) continue;
             const uint32_t Rreal = S & o_valid;
@@ -269,8 +282,12 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
                 err = mean_error<T, UNDISTORT, 0>(cams, C, oobs, kept, q);
                 st_cams += (unsigned long long)C * (unsigned long long)__popcll(__ballot(go));
             }
-            const uint32_t rt = rank_subset(S, C, level, sBinom);             // rank in itertools order: ties, reduction
-            if (alive && better_candidate(err, rt, be, brank)) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
+            // rank in itertools order (ties, reduction): only where a candidate can replace the lane's best
+            uint32_t rt = kNone;
+            bool have_rank = false;
+            const bool may_win = alive && (brank == kNone || !(err > be));
+            if (__any(may_win)) { rt = rank_subset(S, C, level, sBinom); have_rank = true; }
+            if (may_win && better_candidate(err, rt, be, brank)) { be = err; bq0 = q[0]; bq1 = q[1]; bq2 = q[2]; brank = rt; bS = S; }
             if (LRSWAP && !skip_swap && __any(alive && err <= thr)) {
                 skip_swap = true;
                 if (lane == 0) atomicOr(plain_ok, 1u);
@@ -289,7 +306,9 @@ __global__ void __launch_bounds__(256, 3) p2s_deep_eval_kernel(const P2sTriArgs 
                 } else {
                     es = swap_error<T, UNDISTORT, 0>(cams, C, oobs_sw, kept, M, qs);
                 }
-                if (go && (srank == kNone || es < se || (es == se && rt < srank))) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = rt; sS = S; }
+                const bool swap_may_win = go && (srank == kNone || !(es > se));
+                if (!have_rank && __any(swap_may_win)) rt = rank_subset(S, C, level, sBinom);
+                if (swap_may_win && (srank == kNone || es < se || (es == se && rt < srank))) { se = es; sq0 = qs[0]; sq1 = qs[1]; sq2 = qs[2]; srank = rt; sS = S; }
             }
         }
         // wave argmin, lowest rank on ties (np.nanargmin / np.argmin)
