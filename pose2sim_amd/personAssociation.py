@@ -14,7 +14,6 @@ rewrites the JSON files.  With ``undistort_points`` the reference's single-perso
 as a combination keeps fewer than 4 cameras; that accident is not reproduced and the combination is refused
 here with a clear message.
 """
-import json
 import logging
 import os
 
