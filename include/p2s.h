@@ -17,7 +17,10 @@
  *     count whose subset levels can exceed 4 096 subsets (15 cameras or more, min_cameras permitting) reads a 4-byte
  *     count after each chunk's search to drive the deep-level rounds, i.e. it synchronises the stream.
  *   - observation tensor layout: xyl[n_blocks][C][K][3] (x px, y px, likelihood), one block
- *     per (frame, person); NaN = missing.  dtype float32 or float64 (P2S_F32 / P2S_F64).
+ *     per (frame, person); NaN = missing.  dtype float32 or float64 (P2S_F32 / P2S_F64).  A detection whose
+ *     coordinates are not finite is taken as missing whatever its likelihood (the reference reaches the same result one
+ *     search level later); one whose likelihood is exactly 0 must carry finite coordinates (pose estimators write
+ *     (0, 0, 0)) or be NaN throughout.
  *   - camera count C <= P2S_MAX_CAMS (the excluded-camera set is returned as a 32-bit mask).
  */
 #ifndef P2S_H
