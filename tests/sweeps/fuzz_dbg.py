@@ -1,6 +1,6 @@
 """Details of the units of one case of tests/sweeps/fuzz_params.py (seed 1) that differ from the oracle."""
 import os, sys, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import tri_oracle
 from pose2sim_amd import synth
