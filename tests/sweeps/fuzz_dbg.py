@@ -20,6 +20,8 @@ for case in range(400):
         xyl = xyl.copy(); z = rng.random(xyl.shape[:-1]) < 0.05; xyl[z] = 0.0
     if case not in want:
         continue
+    if lik < 0.05:
+        xyl = xyl.copy(); w = xyl[..., 2]; w[(w > 0) & (w < 0.05)] = 0.05      # as fuzz_params.py does
     Qr, er, nr, mr = tri_oracle.triangulate_batch(xyl.astype(np.float64), wl['P'], None, list(range(K)), lik, thr, min_cams, threads=8)
     eng.set_calibration(wl['P'])
     Q, err, nex, mask = eng.triangulate(xyl, eng.tri_params(thr, lik, min_cams))
