@@ -578,3 +578,19 @@ def test_deep_levels_spread_over_the_gpu(C, min_cams, lr_swap, undistort, f64):
         assert (nr.reshape(-1) - np.isnan(x64[..., 2]).sum(axis=2).reshape(-1) >= 2).any()     # some unit did go past level 1
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize('modes,seed', [(False, 11), (True, 12)])
+def test_random_parameter_sets(modes, seed):
+    """A short run of tests/sweeps/fuzz_params.py inside the suite: 60 random (cameras, keypoints, frames, min_cameras,
+    thresholds, contamination, exact zero likelihoods) sets -- with undistortion, L/R swap, float64 observations and up to
+    24 cameras switched on at random in the second run -- every unit against the C oracle on two kernel paths each.
+    (The sweep itself: 1 400 sets, profiles/r03/fuzz_params_*.log.)"""
+    import importlib.util
+    import __graft_entry__ as entry
+    entry.build_hip()
+    spec = importlib.util.spec_from_file_location('fuzz_params', os.path.join(os.path.dirname(__file__), 'sweeps', 'fuzz_params.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(60, seed, modes, verbose=False)
+    assert bad == 0 and worst <= TOL_Q, (bad, worst)
