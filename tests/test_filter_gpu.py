@@ -283,3 +283,16 @@ def test_kalman_kernel_against_the_restatement(engine):
         small = rng.normal(1, 0.1, (F2, 9))
         want = np.stack([fr.kalman_filter_1d(small[:, c], 30, 500, True) for c in range(9)], 1)
         _close(filtering.kalman_filter(small, 30, 500, True, engine), want, f'kalman F={F2}')
+
+
+def test_random_filter_cases():
+    """A short run of tests/sweeps/fuzz_filters.py inside the suite: 25 random (length 1..600, columns, gaps, parameters)
+    cases through the seven column filters against oracle/filtering_ref.py."""
+    import importlib.util
+    import __graft_entry__ as entry
+    entry.build_hip()
+    spec = importlib.util.spec_from_file_location('fuzz_filters', os.path.join(os.path.dirname(__file__), 'sweeps', 'fuzz_filters.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, worst = mod.run(25, 7, verbose=False)
+    assert bad == 0, worst
