@@ -28,7 +28,7 @@ try:
     cfg = ec.base_config(trial, False)
     os.chdir(root)
     stages = {}
-    orig_load, orig_trc = poseio.load_observations, trc.make_trc
+    orig_load, orig_trc = poseio.load_observations, trc.write_trc
 
     def timed(name, fn):
         def wrapper(*a, **k):
@@ -38,7 +38,7 @@ try:
             return out
         return wrapper
     poseio.load_observations = timed('json_ingest_s', orig_load)
-    trc.make_trc = timed('trc_write_s', orig_trc)
+    trc.write_trc = timed('trc_write_s', orig_trc)
     eng_holder = {}
     orig_engine = triangulation._make_engine
 
